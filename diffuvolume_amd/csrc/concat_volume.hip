@@ -1,0 +1,191 @@
+// K2: concatenation cost volume, optionally multiplied by softmax_D(attention logits).
+// Replaces build_concat_volume (SceneFlow/models/submodule.py:180-191; KITTI12 flavour
+// :86-97 with the left half zeroed for x<d) and the `F.softmax(att, dim=2) * volume`
+// pass of acv_ddim.py:390 (two extra passes over a 3 GB tensor at batch 8).
+//
+//   out[b,c,d,y,x]   = p[b,d,y,x] * ref[b,c,y,x]                     c <  C
+//   out[b,C+c,d,y,x] = p[b,d,y,x] * (x>=d ? tgt[b,c,y,x-d] : 0)      c <  C
+//
+// Pure HBM write stream.  A block owns one (b, y) row and a chunk of 8 channels of
+// both halves.  Lane <-> 4 consecutive x (16-byte stores, contiguous along W),
+// wave <-> blocks of 4 disparities.  The shifted target comes from LDS (row staged
+// once behind a zero pad) with two ds_read_b128 per 4x4 register tile.
+#include "dv_common.h"
+
+namespace {
+
+constexpr int kChunk = 8;  // channels of each half per block
+
+template <bool ATT, bool ZERO_LEFT>
+__global__ __launch_bounds__(256) void concat_rows_kernel(const float* __restrict__ ref,
+                                                          const float* __restrict__ tgt,
+                                                          const float* __restrict__ att,
+                                                          float* __restrict__ out, int C, int H,
+                                                          int W, int D) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int nq = W >> 2;
+  const int eblocks = (D + 3) >> 2;
+  const int padq = eblocks + 1;
+  const int rowq = padq + nq;
+  float4* rows = reinterpret_cast<float4*>(smem);
+
+  const int nchunks = (C + kChunk - 1) / kChunk;
+  const int cchunk = blockIdx.x % nchunks;
+  const int by = blockIdx.x / nchunks;
+  const int y = by % H;
+  const int b = by / H;
+  const int c0 = cchunk * kChunk;
+  const int nc = min(kChunk, C - c0);
+  const size_t plane = (size_t)H * W;
+
+  for (int i = threadIdx.x; i < nc * rowq; i += blockDim.x) {
+    const int c = i / rowq, q = i - c * rowq;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q >= padq)
+      v = reinterpret_cast<const float4*>(tgt + ((size_t)b * C + c0 + c) * plane + (size_t)y * W)[q - padq];
+    rows[i] = v;
+  }
+  __syncthreads();
+
+  const size_t vstride = (size_t)D * plane;  // channel stride of the volume
+  const float* attrow = ATT ? att + (size_t)b * D * plane + (size_t)y * W : nullptr;
+  float* outL = out + ((size_t)b * 2 * C + c0) * vstride + (size_t)y * W;
+  float* outR = out + ((size_t)b * 2 * C + C + c0) * vstride + (size_t)y * W;
+
+  for (int t = lane; t < nq; t += DV_WAVE) {
+    float4 mx = make_float4(0.f, 0.f, 0.f, 0.f), rs = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (ATT) {
+      mx = reinterpret_cast<const float4*>(attrow)[t];
+      for (int d = 1; d < D; ++d) {
+        const float4 a = reinterpret_cast<const float4*>(attrow + (size_t)d * plane)[t];
+        mx.x = fmaxf(mx.x, a.x); mx.y = fmaxf(mx.y, a.y); mx.z = fmaxf(mx.z, a.z); mx.w = fmaxf(mx.w, a.w);
+      }
+      float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int d = 0; d < D; ++d) {
+        const float4 a = reinterpret_cast<const float4*>(attrow + (size_t)d * plane)[t];
+        sum.x += expf(a.x - mx.x); sum.y += expf(a.y - mx.y);
+        sum.z += expf(a.z - mx.z); sum.w += expf(a.w - mx.w);
+      }
+      rs = sum;
+    }
+    for (int e = wave; e < eblocks; e += 4) {
+      float p[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int d = 4 * e + r;
+        if (ATT && d < D) {
+          const float4 a = reinterpret_cast<const float4*>(attrow + (size_t)d * plane)[t];
+          p[r][0] = expf(a.x - mx.x) / rs.x; p[r][1] = expf(a.y - mx.y) / rs.y;
+          p[r][2] = expf(a.z - mx.z) / rs.z; p[r][3] = expf(a.w - mx.w) / rs.w;
+        } else {
+          p[r][0] = p[r][1] = p[r][2] = p[r][3] = 1.f;
+        }
+      }
+      for (int c = 0; c < nc; ++c) {
+        const float4 Lq = reinterpret_cast<const float4*>(ref + ((size_t)b * C + c0 + c) * plane + (size_t)y * W)[t];
+        const float l[4] = {Lq.x, Lq.y, Lq.z, Lq.w};
+        const float4 lo = rows[c * rowq + padq + t - e - 1];
+        const float4 hi = rows[c * rowq + padq + t - e];
+        const float w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int d = 4 * e + r;
+          if (d < D) {
+            float vl[4], vr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float lv = l[j];
+              if (ZERO_LEFT && (4 * t + j) < d) lv = 0.f;
+              vl[j] = ATT ? p[r][j] * lv : lv;
+              vr[j] = ATT ? p[r][j] * w[4 + j - r] : w[4 + j - r];
+            }
+            reinterpret_cast<float4*>(outL + (size_t)c * vstride + (size_t)d * plane)[t] =
+                make_float4(vl[0], vl[1], vl[2], vl[3]);
+            reinterpret_cast<float4*>(outR + (size_t)c * vstride + (size_t)d * plane)[t] =
+                make_float4(vr[0], vr[1], vr[2], vr[3]);
+          }
+        }
+      }
+    }
+  }
+}
+
+// Any W / alignment: one thread per output element.
+template <bool ATT, bool ZERO_LEFT>
+__global__ void concat_generic_kernel(const float* __restrict__ ref, const float* __restrict__ tgt,
+                                      const float* __restrict__ att, float* __restrict__ out, int C,
+                                      int H, int W, int D, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W);
+    size_t r = i / W;
+    const int y = (int)(r % H);
+    r /= H;
+    const int d = (int)(r % D);
+    r /= D;
+    const int c = (int)(r % (2 * C));
+    const int b = (int)(r / (2 * C));
+    float v;
+    if (c < C) {
+      v = (ZERO_LEFT && x < d) ? 0.f : ref[(((size_t)b * C + c) * H + y) * W + x];
+    } else {
+      v = x >= d ? tgt[(((size_t)b * C + (c - C)) * H + y) * W + x - d] : 0.f;
+    }
+    if (ATT) {
+      const float* a = att + ((size_t)b * D * H + y) * W + x;
+      const size_t plane = (size_t)H * W;
+      float mx = a[0];
+      for (int k = 1; k < D; ++k) mx = fmaxf(mx, a[k * plane]);
+      float sum = 0.f;
+      for (int k = 0; k < D; ++k) sum += expf(a[k * plane] - mx);
+      v *= expf(a[d * plane] - mx) / sum;
+    }
+    out[i] = v;
+  }
+}
+
+template <bool ATT, bool ZL>
+int launch(const float* ref, const float* tgt, const float* att, float* out, int B, int C, int H,
+           int W, int D, hipStream_t s) {
+  const bool fast = (W % 4 == 0) && dv_aligned16(ref) && dv_aligned16(tgt) && dv_aligned16(out) &&
+                    (!ATT || dv_aligned16(att));
+  const int rowq = ((D + 3) / 4 + 1) + W / 4;
+  const size_t lds = (size_t)kChunk * rowq * sizeof(float4);
+  if (fast && lds <= 64 * 1024) {
+    const int nchunks = (C + kChunk - 1) / kChunk;
+    hipLaunchKernelGGL((concat_rows_kernel<ATT, ZL>), dim3(B * H * nchunks), dim3(256), lds, s, ref,
+                       tgt, att, out, C, H, W, D);
+  } else {
+    const size_t total = (size_t)B * 2 * C * D * H * W;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL((concat_generic_kernel<ATT, ZL>), dim3(blocks), dim3(256), 0, s, ref, tgt, att,
+                       out, C, H, W, D, total);
+  }
+  return dv_launch_status();
+}
+
+}  // namespace
+
+extern "C" int dv_concat_volume_f32(const float* ref, const float* tgt, float* out, int B, int C,
+                                    int H, int W, int D, int zero_left, dv_stream_t stream) {
+  DV_REQUIRE_PTR(ref);
+  DV_REQUIRE_PTR(tgt);
+  DV_REQUIRE_PTR(out);
+  DV_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && D > 0, DV_ERR_SHAPE);
+  hipStream_t s = (hipStream_t)stream;
+  return zero_left ? launch<false, true>(ref, tgt, nullptr, out, B, C, H, W, D, s)
+                   : launch<false, false>(ref, tgt, nullptr, out, B, C, H, W, D, s);
+}
+
+extern "C" int dv_concat_attn_volume_f32(const float* ref, const float* tgt, const float* att,
+                                         float* out, int B, int C, int H, int W, int D,
+                                         dv_stream_t stream) {
+  DV_REQUIRE_PTR(ref);
+  DV_REQUIRE_PTR(tgt);
+  DV_REQUIRE_PTR(att);
+  DV_REQUIRE_PTR(out);
+  DV_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && D > 0, DV_ERR_SHAPE);
+  return launch<true, false>(ref, tgt, att, out, B, C, H, W, D, (hipStream_t)stream);
+}

@@ -1,0 +1,292 @@
+// K4: 3-D convolution (k in {1,3}, stride in {1,2}, pad (k-1)/2) as an implicit GEMM on the
+// exact-fp32 matrix instruction v_mfma_f32_16x16x4_f32, with the reference's surrounding
+// elementwise work fused in:
+//   y = act( conv(x * in_scale) * ch_scale + ch_bias + residual )
+// Replaces convbn_3d + ReLU (SceneFlow/models/submodule.py:94-97; uses acv_ddim.py:60-70,
+// :82-83, :200-222) and the `volume * noise.unsqueeze(1)` multiply of acv_ddim.py:260.
+//
+// GEMM view:  M = output voxels (16 consecutive x of one (z,y) row per MFMA tile),
+//             N = output channels (16 per tile),  K = taps x input channels.
+// A block of 4 waves owns a TD x TH x (16*MTX) output brick and NT*16 output channels.
+// Per chunk of KC input channels the haloed input brick and the weight slice are staged
+// in LDS (channel-plane stride P chosen so the four k-lanes of an MFMA operand hit
+// disjoint banks), then every tap is one MFMA k-step:  A = in_s[cin][voxel+tap]
+// (ds_read_b32, lanes contiguous along x), B = w_s[tap][cin][cout].  Several blocks are
+// resident per CU so one block's staging overlaps another's MFMA stream.
+// MFMA-bound: 27*Cin*2 flop per output float (AI 86-864 flop/byte at fp32).
+#include "dv_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int round_mod(int v, int mod, int rem) {  // smallest v' >= v with v' % mod == rem
+  int r = v % mod;
+  return r <= rem ? v + (rem - r) : v + (mod - r) + rem;
+}
+
+template <int KS_, int S_, int NT_, int MTX_, int TH_, int TD_, int KC_>
+struct Geo {
+  static constexpr int KS = KS_, S = S_, NT = NT_, MTX = MTX_, TH = TH_, TD = TD_, KC = KC_;
+  static constexpr int PAD = (KS - 1) / 2;
+  static constexpr int T = KS * KS * KS;
+  static constexpr int TW = MTX * 16;
+  static constexpr int IZ = (TD - 1) * S + KS, IY = (TH - 1) * S + KS, IX = (TW - 1) * S + KS;
+  static constexpr int PRAW = IZ * IY * IX;
+  // bank rule: lanes 0-15 (k=0) and 16-31 (k=1) of a ds_read_b32 must not collide
+  static constexpr int P = S == 1 ? round_mod(PRAW, 32, 16) : (PRAW | 1);
+  static constexpr int COUT = NT * 16;
+  static constexpr int IN_FLOATS = KC * P;
+  static constexpr int W_FLOATS = T * KC * COUT;
+  static constexpr int ROWS = TD * TH;
+  static constexpr int RPW = ROWS / 4;
+  static constexpr int MT = RPW * MTX;
+  static_assert(ROWS % 4 == 0, "rows must split over 4 waves");
+  static_assert(KC % 4 == 0, "K chunk is a multiple of the MFMA k");
+  static_assert((IN_FLOATS + W_FLOATS) * 4 <= 160 * 1024, "LDS budget");
+};
+
+struct ConvArgs {
+  const float* in;
+  const float* wpk;      // [Cinp/2][T][Coutp][2]
+  const float* ch_scale; // [Cout] or null
+  const float* ch_bias;  // [Cout] or null
+  const float* in_scale; // [B,D,H,W] or null
+  const float* residual; // [B,Cout,Do,Ho,Wo] or null
+  float* out;
+  int B, Cin, D, H, W, Cout, Coutp, Do, Ho, Wo;
+  int ntx, nty, ntz, nco;  // tile counts
+  int act;
+  int vec_store;           // Wo % 4 == 0 and 16-byte aligned pointers
+};
+
+template <class G>
+__global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[G::IN_FLOATS + G::W_FLOATS];
+  float* in_s = smem;
+  float* w_s = smem + G::IN_FLOATS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+
+  // block -> (b, co-slice, z, y, x) tile; consecutive tiles on one XCD share halos in its L2
+  unsigned t = dv_xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = t % a.ntx; t /= a.ntx;
+  const int ty = t % a.nty; t /= a.nty;
+  const int tz = t % a.ntz; t /= a.ntz;
+  const int tc = t % a.nco;
+  const int b = t / a.nco;
+  const int x0 = tx * G::TW, y0 = ty * G::TH, z0 = tz * G::TD, co0 = tc * G::COUT;
+  const int xi0 = x0 * G::S - G::PAD, yi0 = y0 * G::S - G::PAD, zi0 = z0 * G::S - G::PAD;
+
+  f32x4 acc[G::MT][G::NT];
+#pragma unroll
+  for (int m = 0; m < G::MT; ++m)
+#pragma unroll
+    for (int n = 0; n < G::NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int abase[G::MT];
+#pragma unroll
+  for (int m = 0; m < G::MT; ++m) {
+    const int rr = wave * G::RPW + m / G::MTX, xt = m % G::MTX;
+    const int zl = rr / G::TH, yl = rr % G::TH;
+    abase[m] = kq * G::P + ((zl * G::S) * G::IY + yl * G::S) * G::IX + (xt * 16 + j) * G::S;
+  }
+  const int bbase = ((kq >> 1) * G::T * G::COUT + j) * 2 + (kq & 1);
+
+  const size_t plane = (size_t)a.H * a.W;
+  const size_t vol = (size_t)a.D * plane;
+  const float* inb = a.in + (size_t)b * a.Cin * vol;
+  const float* scb = a.in_scale ? a.in_scale + (size_t)b * vol : nullptr;
+
+  for (int c0 = 0; c0 < a.Cin; c0 += G::KC) {
+    __syncthreads();  // previous chunk's MFMAs are done reading LDS
+    // ---- stage the haloed input brick of KC channels ----
+#pragma unroll 4
+    for (int e = tid; e < G::KC * G::PRAW; e += 256) {
+      const int cl = e / G::PRAW, r = e - cl * G::PRAW;
+      const int zz = r / (G::IY * G::IX), r2 = r - zz * (G::IY * G::IX);
+      const int yy = r2 / G::IX, xx = r2 - yy * G::IX;
+      const int z = zi0 + zz, y = yi0 + yy, x = xi0 + xx, c = c0 + cl;
+      float v = 0.f;
+      if ((unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W &&
+          c < a.Cin) {
+        const size_t sp = (size_t)z * plane + (size_t)y * a.W + x;
+        v = inb[(size_t)c * vol + sp];
+        if (scb) v *= scb[sp];
+      }
+      in_s[cl * G::P + r] = v;
+    }
+    // ---- stage the weight slice: [KC/2][T][COUT][2] from [Cinp/2][T][Coutp][2] ----
+    {
+      const float* wsrc = a.wpk + ((size_t)(c0 >> 1) * G::T * a.Coutp + co0) * 2;
+      constexpr int ROWQ = G::COUT * 2 / 4;                 // float4 per (cinpair, tap) row
+      constexpr int NQ = (G::KC / 2) * G::T * ROWQ;
+      for (int e = tid; e < NQ; e += 256) {
+        const int row = e / ROWQ, q = e - row * ROWQ;
+        const float4 v = reinterpret_cast<const float4*>(wsrc + (size_t)row * a.Coutp * 2)[q];
+        reinterpret_cast<float4*>(w_s)[e] = v;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA stream: one k-step (4 input channels) per tap ----
+#pragma unroll
+    for (int dz = 0; dz < G::KS; ++dz)
+#pragma unroll
+      for (int dy = 0; dy < G::KS; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < G::KS; ++dx) {
+          const int tap = (dz * G::KS + dy) * G::KS + dx;
+          const int toff = (dz * G::IY + dy) * G::IX + dx;
+#pragma unroll
+          for (int ks = 0; ks < G::KC / 4; ++ks) {
+            float bf[G::NT];
+#pragma unroll
+            for (int n = 0; n < G::NT; ++n)
+              bf[n] = w_s[bbase + ((ks * 2 * G::T + tap) * G::COUT + n * 16) * 2];
+#pragma unroll
+            for (int m = 0; m < G::MT; ++m) {
+              const float av = in_s[abase[m] + ks * 4 * G::P + toff];
+#pragma unroll
+              for (int n = 0; n < G::NT; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bf[n], acc[m][n], 0, 0, 0);
+            }
+          }
+        }
+  }
+
+  // ---- epilogue: BN scale/bias, residual, activation, store (lane = 4 x of one channel) ----
+  const size_t oplane = (size_t)a.Ho * a.Wo;
+  const size_t ovol = (size_t)a.Do * oplane;
+#pragma unroll
+  for (int n = 0; n < G::NT; ++n) {
+    const int co = co0 + n * 16 + j;
+    if (co >= a.Cout) continue;
+    const float sc = a.ch_scale ? a.ch_scale[co] : 1.f;
+    const float bi = a.ch_bias ? a.ch_bias[co] : 0.f;
+    const size_t cbase = ((size_t)b * a.Cout + co) * ovol;
+#pragma unroll
+    for (int m = 0; m < G::MT; ++m) {
+      const int rr = wave * G::RPW + m / G::MTX, xt = m % G::MTX;
+      const int zo = z0 + rr / G::TH, yo = y0 + rr % G::TH, xo = x0 + xt * 16 + 4 * kq;
+      if (zo >= a.Do || yo >= a.Ho || xo >= a.Wo) continue;
+      const size_t o = cbase + (size_t)zo * oplane + (size_t)yo * a.Wo + xo;
+      float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = fmaf(v[r], sc, bi);
+      if (a.vec_store) {
+        if (a.residual) {
+          const float4 rv = *reinterpret_cast<const float4*>(a.residual + o);
+          v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+        }
+        *reinterpret_cast<float4*>(a.out + o) =
+            make_float4(dv_act(v[0], a.act), dv_act(v[1], a.act), dv_act(v[2], a.act), dv_act(v[3], a.act));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (xo + r < a.Wo) {
+            float u = v[r];
+            if (a.residual) u += a.residual[o + r];
+            a.out[o + r] = dv_act(u, a.act);
+          }
+      }
+    }
+  }
+}
+
+__global__ void pack_conv_weights_kernel(const float* __restrict__ w, float* __restrict__ wpk, int Cin,
+                                         int Cout, int T, int Cinp, int Coutp) {
+  const size_t total = (size_t)Cinp * T * Coutp;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int par = (int)(i & 1);
+    size_t r = i >> 1;
+    const int co = (int)(r % Coutp); r /= Coutp;
+    const int tap = (int)(r % T);
+    const int cp = (int)(r / T);
+    const int ci = cp * 2 + par;
+    wpk[i] = (ci < Cin && co < Cout) ? w[((size_t)co * Cin + ci) * T + tap] : 0.f;
+  }
+}
+
+inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+inline int coutp_of(int Cout) { return Cout <= 16 ? 16 : (Cout <= 32 ? 32 : pad_to(Cout, 64)); }
+
+template <class G>
+int launch_conv(ConvArgs a, hipStream_t s) {
+  a.ntx = (a.Wo + G::TW - 1) / G::TW;
+  a.nty = (a.Ho + G::TH - 1) / G::TH;
+  a.ntz = (a.Do + G::TD - 1) / G::TD;
+  a.nco = a.Coutp / G::COUT;
+  const long long blocks = (long long)a.B * a.nco * a.ntz * a.nty * a.ntx;
+  if (blocks <= 0 || blocks > 0x7fffffffLL) return DV_ERR_SHAPE;
+  hipLaunchKernelGGL(conv3d_mfma_kernel<G>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  return dv_launch_status();
+}
+
+}  // namespace
+
+extern "C" size_t dv_conv3d_packed_floats(int Cin, int Cout, int k) {
+  if (Cin <= 0 || Cout <= 0 || (k != 1 && k != 3)) return 0;
+  return (size_t)pad_to(Cin, 8) * (k * k * k) * coutp_of(Cout);
+}
+
+extern "C" int dv_conv3d_pack_weights_f32(const float* w, float* wpacked, int Cin, int Cout, int k,
+                                          dv_stream_t stream) {
+  DV_REQUIRE_PTR(w);
+  DV_REQUIRE_PTR(wpacked);
+  DV_REQUIRE(Cin > 0 && Cout > 0, DV_ERR_SHAPE);
+  DV_REQUIRE(k == 1 || k == 3, DV_ERR_UNSUPPORTED);
+  const int T = k * k * k, Cinp = pad_to(Cin, 8), Coutp = coutp_of(Cout);
+  const size_t total = (size_t)Cinp * T * Coutp;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_conv_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
+                     wpacked, Cin, Cout, T, Cinp, Coutp);
+  return dv_launch_status();
+}
+
+extern "C" int dv_conv3d_f32(const float* in, const float* wpacked, const float* ch_scale,
+                             const float* ch_bias, const float* in_scale, const float* residual,
+                             float* out, int B, int Cin, int D, int H, int W, int Cout, int k,
+                             int stride, int act, dv_stream_t stream) {
+  DV_REQUIRE_PTR(in);
+  DV_REQUIRE_PTR(wpacked);
+  DV_REQUIRE_PTR(out);
+  DV_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0 && Cout > 0, DV_ERR_SHAPE);
+  DV_REQUIRE(k == 1 || k == 3, DV_ERR_UNSUPPORTED);
+  DV_REQUIRE(stride == 1 || stride == 2, DV_ERR_UNSUPPORTED);
+  DV_REQUIRE(!(k == 1 && stride != 1), DV_ERR_UNSUPPORTED);
+  DV_REQUIRE(act >= DV_ACT_NONE && act <= DV_ACT_LEAKY, DV_ERR_UNSUPPORTED);
+  DV_REQUIRE(dv_aligned16(wpacked), DV_ERR_ALIGN);
+  ConvArgs a;
+  a.in = in; a.wpk = wpacked; a.ch_scale = ch_scale; a.ch_bias = ch_bias; a.in_scale = in_scale;
+  a.residual = residual; a.out = out;
+  a.B = B; a.Cin = Cin; a.D = D; a.H = H; a.W = W; a.Cout = Cout; a.Coutp = coutp_of(Cout);
+  const int pad = (k - 1) / 2;
+  a.Do = (D + 2 * pad - k) / stride + 1;
+  a.Ho = (H + 2 * pad - k) / stride + 1;
+  a.Wo = (W + 2 * pad - k) / stride + 1;
+  a.act = act;
+  a.vec_store = (a.Wo % 4 == 0) && dv_aligned16(out) && (!residual || dv_aligned16(residual));
+  a.ntx = a.nty = a.ntz = a.nco = 0;
+  hipStream_t s = (hipStream_t)stream;
+  //            KS S NT MTX TH TD KC
+  if (k == 3 && stride == 1) {
+    if (a.Coutp == 16) return launch_conv<Geo<3, 1, 1, 2, 4, 4, 8>>(a, s);
+    if (a.Coutp == 32) {
+      if (a.Wo % 48 == 0) return launch_conv<Geo<3, 1, 2, 3, 4, 4, 4>>(a, s);
+      return launch_conv<Geo<3, 1, 2, 2, 4, 4, 8>>(a, s);
+    }
+    return launch_conv<Geo<3, 1, 4, 2, 4, 4, 4>>(a, s);
+  }
+  if (k == 3 && stride == 2) {
+    if (a.Coutp == 16) return launch_conv<Geo<3, 2, 1, 2, 4, 2, 4>>(a, s);
+    if (a.Coutp == 32) return launch_conv<Geo<3, 2, 2, 2, 4, 2, 4>>(a, s);
+    return launch_conv<Geo<3, 2, 4, 2, 4, 2, 4>>(a, s);
+  }
+  // k == 1
+  if (a.Coutp == 16) return launch_conv<Geo<1, 1, 1, 2, 4, 4, 8>>(a, s);
+  if (a.Coutp == 32) return launch_conv<Geo<1, 1, 2, 2, 4, 4, 8>>(a, s);
+  return launch_conv<Geo<1, 1, 4, 2, 4, 4, 8>>(a, s);
+}

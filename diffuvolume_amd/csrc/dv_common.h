@@ -1,0 +1,46 @@
+// Shared helpers for the gfx950 kernels of libdiffuvolume_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/diffuvolume_hip.h"
+
+#define DV_WAVE 64
+
+#define DV_REQUIRE_PTR(p) \
+  do {                    \
+    if ((p) == nullptr) return DV_ERR_NULL; \
+  } while (0)
+#define DV_REQUIRE(cond, err) \
+  do {                        \
+    if (!(cond)) return (err); \
+  } while (0)
+
+// Launch errors are reported to the caller as a positive hipError_t.
+static inline int dv_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? DV_OK : (int)e;
+}
+
+static inline bool dv_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+__device__ __forceinline__ float dv_act(float v, int act) {
+  switch (act) {
+    case DV_ACT_RELU: return fmaxf(v, 0.0f);
+    case DV_ACT_MISH: {
+      // x * tanh(softplus(x)); softplus threshold 20 as torch (KITTI12/models/submodule.py:11-18)
+      float sp = v > 20.0f ? v : log1pf(expf(v));
+      return v * tanhf(sp);
+    }
+    case DV_ACT_LEAKY: return v > 0.0f ? v : 0.01f * v;
+    default: return v;
+  }
+}
+
+// XCD-aware block remap: blocks b and b+8 share an XCD (and its L2), so give
+// every XCD a contiguous slab of tiles.  Bijective for any grid size.
+__device__ __forceinline__ unsigned dv_xcd_remap(unsigned bid, unsigned nblk) {
+  const unsigned q = nblk >> 3, r = nblk & 7u;
+  const unsigned xcd = bid & 7u, idx = bid >> 3;
+  const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}

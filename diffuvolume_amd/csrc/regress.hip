@@ -1,0 +1,200 @@
+// K7: trilinear x4 upsample -> softmax over disparity -> soft-argmax (+ uncertainty), fused.
+// Replaces F.upsample(..., 'trilinear') + F.softmax(dim=1) + disparity_regression
+// (SceneFlow/models/acv_ddim.py:267-270, submodule.py:173-177) and the uncertainty block
+// acv_ddim.py:325-329.  The reference materialises three [B,192,H,W] tensors per call
+// (377 MB each per pair); here each output pixel keeps its D in-plane interpolated
+// costs in registers and walks the 4D bins four times (max, sum, expectation, |.| moment),
+// so HBM traffic is the [B,D,h,w] cost in and two [B,4h,4w] maps out.
+#include "dv_common.h"
+
+namespace {
+
+// PyTorch's linear source index (area_pixel_compute_source_index, non-cubic).
+template <bool ALIGN>
+__device__ __forceinline__ void lin_src(int dst, int in_size, int out_size, int& i0, int& i1, float& l0,
+                                        float& l1) {
+  float src;
+  if (ALIGN) {
+    const float scale = out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+    src = scale * (float)dst;
+  } else {
+    const float scale = (float)in_size / (float)out_size;
+    src = scale * ((float)dst + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+  }
+  i0 = (int)src;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+
+template <int D, bool ALIGN>
+__global__ __launch_bounds__(256) void upsample_softmax_regress_kernel(const float* __restrict__ cost,
+                                                                       float* __restrict__ disp,
+                                                                       float* __restrict__ unc, int h,
+                                                                       int w, size_t total) {
+  const int H = 4 * h, W = 4 * w;
+  constexpr int K = 4 * D;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int X = (int)(i % W);
+  const int Y = (int)((i / W) % H);
+  const int b = (int)(i / ((size_t)W * H));
+  int y0, y1, x0, x1;
+  float hy0, hy1, wx0, wx1;
+  lin_src<ALIGN>(Y, h, H, y0, y1, hy0, hy1);
+  lin_src<ALIGN>(X, w, W, x0, x1, wx0, wx1);
+  const size_t plane = (size_t)h * w;
+  const float* cb = cost + (size_t)b * D * plane;
+  float c[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const float* p = cb + (size_t)d * plane;
+    const float v00 = p[(size_t)y0 * w + x0], v01 = p[(size_t)y0 * w + x1];
+    const float v10 = p[(size_t)y1 * w + x0], v11 = p[(size_t)y1 * w + x1];
+    c[d] = hy0 * (wx0 * v00 + wx1 * v01) + hy1 * (wx0 * v10 + wx1 * v11);
+  }
+  // v_k = l0*c[i0] + l1*c[i1]; k is a compile-time constant after unrolling, so the
+  // index / weight computation folds away and c[] stays in registers.
+#define DV_VK(k, out)                                  \
+  {                                                    \
+    int i0_, i1_;                                      \
+    float l0_, l1_;                                    \
+    lin_src<ALIGN>((k), D, K, i0_, i1_, l0_, l1_);     \
+    (out) = l0_ * c[i0_] + l1_ * c[i1_];               \
+  }
+  float m = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float v;
+    DV_VK(k, v);
+    m = fmaxf(m, v);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float v;
+    DV_VK(k, v);
+    s += expf(v - m);
+  }
+  float dsp = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float v;
+    DV_VK(k, v);
+    dsp += (expf(v - m) / s) * (float)k;
+  }
+  disp[i] = dsp;
+  if (unc) {
+    float u = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float v;
+      DV_VK(k, v);
+      u += fabsf(dsp - (float)k) * (expf(v - m) / s);
+    }
+    unc[i] = u;
+  }
+#undef DV_VK
+}
+
+// Any D: the D in-plane costs of a pixel live in LDS (one column per thread).
+template <bool ALIGN>
+__global__ void upsample_softmax_regress_generic(const float* __restrict__ cost, float* __restrict__ disp,
+                                                 float* __restrict__ unc, int D, int h, int w,
+                                                 size_t total) {
+  extern __shared__ float cs[];  // [D][blockDim.x]
+  const int H = 4 * h, W = 4 * w, K = 4 * D;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < total;
+  const size_t ii = live ? i : 0;
+  const int X = (int)(ii % W);
+  const int Y = (int)((ii / W) % H);
+  const int b = (int)(ii / ((size_t)W * H));
+  int y0, y1, x0, x1;
+  float hy0, hy1, wx0, wx1;
+  lin_src<ALIGN>(Y, h, H, y0, y1, hy0, hy1);
+  lin_src<ALIGN>(X, w, W, x0, x1, wx0, wx1);
+  const size_t plane = (size_t)h * w;
+  const float* cb = cost + (size_t)b * D * plane;
+  float* c = cs + threadIdx.x;
+  const int st = blockDim.x;
+  for (int d = 0; d < D; ++d) {
+    const float* p = cb + (size_t)d * plane;
+    c[d * st] = hy0 * (wx0 * p[(size_t)y0 * w + x0] + wx1 * p[(size_t)y0 * w + x1]) +
+                hy1 * (wx0 * p[(size_t)y1 * w + x0] + wx1 * p[(size_t)y1 * w + x1]);
+  }
+  auto vk = [&](int k) {
+    int i0, i1;
+    float l0, l1;
+    lin_src<ALIGN>(k, D, K, i0, i1, l0, l1);
+    return l0 * c[i0 * st] + l1 * c[i1 * st];
+  };
+  float m = -INFINITY;
+  for (int k = 0; k < K; ++k) m = fmaxf(m, vk(k));
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) s += expf(vk(k) - m);
+  float dsp = 0.f;
+  for (int k = 0; k < K; ++k) dsp += (expf(vk(k) - m) / s) * (float)k;
+  if (!live) return;
+  disp[i] = dsp;
+  if (unc) {
+    float u = 0.f;
+    for (int k = 0; k < K; ++k) u += fabsf(dsp - (float)k) * (expf(vk(k) - m) / s);
+    unc[i] = u;
+  }
+}
+
+__global__ void disparity_regression_kernel(const float* __restrict__ prob, float* __restrict__ disp,
+                                            int D, size_t plane, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const size_t b = i / plane, p = i - b * plane;
+  const float* src = prob + b * D * plane + p;
+  float acc = 0.f;
+  for (int d = 0; d < D; ++d) acc += src[(size_t)d * plane] * (float)d;
+  disp[i] = acc;
+}
+
+}  // namespace
+
+extern "C" int dv_upsample_softmax_regress_f32(const float* cost, float* disp, float* unc, int B, int D,
+                                               int h, int w, int align_corners, dv_stream_t stream) {
+  DV_REQUIRE_PTR(cost);
+  DV_REQUIRE_PTR(disp);
+  DV_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, DV_ERR_SHAPE);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t total = (size_t)B * 16 * h * w;
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (D == 48) {
+    if (align_corners)
+      hipLaunchKernelGGL((upsample_softmax_regress_kernel<48, true>), dim3(blocks), dim3(256), 0, s, cost,
+                         disp, unc, h, w, total);
+    else
+      hipLaunchKernelGGL((upsample_softmax_regress_kernel<48, false>), dim3(blocks), dim3(256), 0, s, cost,
+                         disp, unc, h, w, total);
+    return dv_launch_status();
+  }
+  const int threads = 64;
+  const size_t lds = (size_t)D * threads * sizeof(float);
+  DV_REQUIRE(lds <= 64 * 1024, DV_ERR_UNSUPPORTED);
+  const unsigned gblocks = (unsigned)((total + threads - 1) / threads);
+  if (align_corners)
+    hipLaunchKernelGGL((upsample_softmax_regress_generic<true>), dim3(gblocks), dim3(threads), lds, s, cost,
+                       disp, unc, D, h, w, total);
+  else
+    hipLaunchKernelGGL((upsample_softmax_regress_generic<false>), dim3(gblocks), dim3(threads), lds, s, cost,
+                       disp, unc, D, h, w, total);
+  return dv_launch_status();
+}
+
+extern "C" int dv_disparity_regression_f32(const float* prob, float* disp, int B, int D, int H, int W,
+                                           dv_stream_t stream) {
+  DV_REQUIRE_PTR(prob);
+  DV_REQUIRE_PTR(disp);
+  DV_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, DV_ERR_SHAPE);
+  const size_t plane = (size_t)H * W, total = (size_t)B * plane;
+  hipLaunchKernelGGL(disparity_regression_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, prob, disp, D, plane, total);
+  return dv_launch_status();
+}

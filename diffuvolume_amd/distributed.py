@@ -1,0 +1,49 @@
+"""One process per GPU; stereo pairs are independent, so the batch is split into contiguous
+shards with no data-path collective.  The reference uses nn.DataParallel, which
+re-broadcasts the weights and gathers outputs on every forward
+(SceneFlow/test_sceneflow_ddim.py:54-61); here weights are replicated once and the only
+collective is the metric all-reduce in ``metrics.MetricAccumulator.reduce``."""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank) from torchrun's environment; initialises the default
+    process group when WORLD_SIZE > 1 (backend 'nccl' == RCCL on ROCm, 'gloo' on CPU)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [lo, hi) slice of ``n_items`` for ``rank``: sizes differ by at most one and
+    the first ``n_items % world`` ranks take the extra item."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank / world size")
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def barrier_and_max(seconds: float, device) -> float:
+    """Barrier, then the MAX over ranks of a local duration (bench.py contract)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.tensor([seconds], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    return seconds

@@ -1,0 +1,255 @@
+"""L1 ops of the DiffuVolume hot path behind the reference's function signatures.
+
+Same names, argument meaning and error behaviour as SceneFlow/models/submodule.py
+(``build_gwc_volume`` :228-238, ``build_concat_volume`` :180-191,
+``disparity_regression`` :173-177) and their KITTI12 / KITTI15 twins; the work is
+done by the HIP kernels of libdiffuvolume_hip.so on the current stream.  Inference
+only: tensors that require grad are rejected (the north star is the eval path).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+__all__ = ["build_gwc_volume", "build_concat_volume", "build_concat_attention_volume",
+           "disparity_regression", "upsample_softmax_regress", "Conv3dPlan", "Deconv3dPlan",
+           "window_attention", "ACT_NONE", "ACT_RELU", "ACT_MISH", "ACT_LEAKY"]
+
+ACT_NONE, ACT_RELU, ACT_MISH, ACT_LEAKY = 0, 1, 2, 3
+
+
+def _dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a tensor")
+    if not t.is_cuda:
+        raise _lib.DiffuVolumeError(
+            f"{name} is on {t.device}: the DiffuVolume hot path only runs on the MI355X "
+            "(HIP kernels, no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if torch.is_grad_enabled() and t.requires_grad:
+        raise NotImplementedError("the HIP hot path is inference-only; call it under torch.no_grad()")
+    return t.contiguous()
+
+
+def build_gwc_volume(refimg_fea: torch.Tensor, targetimg_fea: torch.Tensor, maxdisp: int,
+                     num_groups: int) -> torch.Tensor:
+    """[B,C,H,W] x2 -> [B,num_groups,maxdisp,H,W] (submodule.py:228-238)."""
+    ref = _dev_f32(refimg_fea, "refimg_fea")
+    tgt = _dev_f32(targetimg_fea, "targetimg_fea")
+    if ref.dim() != 4 or ref.shape != tgt.shape:
+        raise RuntimeError(f"feature shapes differ or are not 4-D: {tuple(ref.shape)} vs {tuple(tgt.shape)}")
+    b, c, h, w = ref.shape
+    assert c % num_groups == 0          # submodule.py:211
+    out = torch.empty((b, num_groups, maxdisp, h, w), dtype=torch.float32, device=ref.device)
+    lib = _lib.load()
+    with torch.cuda.device(ref.device):
+        _lib.check(lib.dv_gwc_volume_f32(ref.data_ptr(), tgt.data_ptr(), out.data_ptr(), b, c, h, w,
+                                         maxdisp, num_groups, _lib.stream_ptr()), "dv_gwc_volume_f32")
+    return out
+
+
+def build_concat_volume(refimg_fea: torch.Tensor, targetimg_fea: torch.Tensor, maxdisp: int,
+                        zero_left: bool = False) -> torch.Tensor:
+    """[B,C,H,W] x2 -> [B,2C,maxdisp,H,W] (submodule.py:180-191).  ``zero_left=True``
+    is the KITTI12 flavour (KITTI12/models/submodule.py:86-97)."""
+    ref = _dev_f32(refimg_fea, "refimg_fea")
+    tgt = _dev_f32(targetimg_fea, "targetimg_fea")
+    if ref.dim() != 4 or ref.shape != tgt.shape:
+        raise RuntimeError(f"feature shapes differ or are not 4-D: {tuple(ref.shape)} vs {tuple(tgt.shape)}")
+    b, c, h, w = ref.shape
+    out = torch.empty((b, 2 * c, maxdisp, h, w), dtype=torch.float32, device=ref.device)
+    lib = _lib.load()
+    with torch.cuda.device(ref.device):
+        _lib.check(lib.dv_concat_volume_f32(ref.data_ptr(), tgt.data_ptr(), out.data_ptr(), b, c, h, w,
+                                            maxdisp, int(bool(zero_left)), _lib.stream_ptr()),
+                   "dv_concat_volume_f32")
+    return out
+
+
+def build_concat_attention_volume(refimg_fea: torch.Tensor, targetimg_fea: torch.Tensor,
+                                  att_weights: torch.Tensor, maxdisp: int) -> torch.Tensor:
+    """``F.softmax(att_weights, dim=2) * build_concat_volume(...)`` in one pass
+    (acv_ddim.py:388-390).  att_weights [B,1,maxdisp,H,W] are logits."""
+    ref = _dev_f32(refimg_fea, "refimg_fea")
+    tgt = _dev_f32(targetimg_fea, "targetimg_fea")
+    att = _dev_f32(att_weights, "att_weights")
+    b, c, h, w = ref.shape
+    if ref.shape != tgt.shape or tuple(att.shape) != (b, 1, maxdisp, h, w):
+        raise RuntimeError("shape mismatch between features and attention weights")
+    out = torch.empty((b, 2 * c, maxdisp, h, w), dtype=torch.float32, device=ref.device)
+    lib = _lib.load()
+    with torch.cuda.device(ref.device):
+        _lib.check(lib.dv_concat_attn_volume_f32(ref.data_ptr(), tgt.data_ptr(), att.data_ptr(),
+                                                 out.data_ptr(), b, c, h, w, maxdisp, _lib.stream_ptr()),
+                   "dv_concat_attn_volume_f32")
+    return out
+
+
+def disparity_regression(x: torch.Tensor, maxdisp: int, keepdim: bool = False) -> torch.Tensor:
+    """[B,D,H,W] probabilities -> sum_d d*p_d (submodule.py:173-177; keepdim=True is the
+    KITTI15 flavour, core/submodule.py:219-223)."""
+    assert len(x.shape) == 4            # submodule.py:174
+    x = _dev_f32(x, "x")
+    b, d, h, w = x.shape
+    if d != maxdisp:
+        raise RuntimeError(f"The size of tensor a ({d}) must match the size of tensor b ({maxdisp}) "
+                           "at non-singleton dimension 1")
+    out = torch.empty((b, h, w), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.dv_disparity_regression_f32(x.data_ptr(), out.data_ptr(), b, d, h, w,
+                                                   _lib.stream_ptr()), "dv_disparity_regression_f32")
+    return out.unsqueeze(1) if keepdim else out
+
+
+def upsample_softmax_regress(cost: torch.Tensor, want_uncertainty: bool = True,
+                             align_corners: bool = False
+                             ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """cost [B,1,D,h,w] (or [B,D,h,w]) -> (disp [B,4h,4w], uncertainty | None): trilinear x4,
+    softmax over 4D bins, soft-argmax and sum_k |disp-k| p_k (acv_ddim.py:267-270, :325-329)."""
+    cost = _dev_f32(cost, "cost")
+    if cost.dim() == 5:
+        if cost.shape[1] != 1:
+            raise RuntimeError("cost must have one channel")
+        cost = cost[:, 0]
+    b, d, h, w = cost.shape
+    disp = torch.empty((b, 4 * h, 4 * w), dtype=torch.float32, device=cost.device)
+    unc = torch.empty_like(disp) if want_uncertainty else None
+    lib = _lib.load()
+    with torch.cuda.device(cost.device):
+        _lib.check(lib.dv_upsample_softmax_regress_f32(cost.data_ptr(), disp.data_ptr(), _lib.ptr(unc),
+                                                       b, d, h, w, int(bool(align_corners)),
+                                                       _lib.stream_ptr()),
+                   "dv_upsample_softmax_regress_f32")
+    return disp, unc
+
+
+class Conv3dPlan:
+    """A Conv3d(bias=False)[+BatchNorm3d eval][+activation] layer prepared for the
+    implicit-GEMM kernel: weights repacked once on the device, BN folded to a
+    per-channel scale/bias applied in the epilogue (submodule.py:94-97)."""
+
+    def __init__(self, weight: torch.Tensor, bn: Optional[Tuple[torch.Tensor, ...]] = None,
+                 stride: int = 1, act: int = ACT_NONE, bias: Optional[torch.Tensor] = None,
+                 eps: float = 1e-5):
+        w = _dev_f32(weight.detach(), "weight")
+        self.cout, self.cin, k = w.shape[0], w.shape[1], w.shape[2]
+        if tuple(w.shape[2:]) != (k, k, k) or k not in (1, 3):
+            raise _lib.DiffuVolumeError(f"unsupported Conv3d kernel {tuple(w.shape[2:])}")
+        self.k, self.stride, self.act = k, stride, act
+        lib = _lib.load()
+        n = lib.dv_conv3d_packed_floats(self.cin, self.cout, k)
+        self.wpacked = torch.empty(n, dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            _lib.check(lib.dv_conv3d_pack_weights_f32(w.data_ptr(), self.wpacked.data_ptr(), self.cin,
+                                                      self.cout, k, _lib.stream_ptr()),
+                       "dv_conv3d_pack_weights_f32")
+        self.scale, self.shift = _fold_bn(bn, bias, self.cout, w.device, eps)
+
+    def out_shape(self, shape):
+        b, _, d, h, w = shape
+        s = self.stride
+        f = (lambda n: (n - 1) // s + 1)
+        return (b, self.cout, f(d), f(h), f(w))
+
+    def __call__(self, x: torch.Tensor, in_scale: Optional[torch.Tensor] = None,
+                 residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None
+                 ) -> torch.Tensor:
+        x = _dev_f32(x, "x")
+        b, cin, d, h, w = x.shape
+        if cin != self.cin:
+            raise RuntimeError(f"expected {self.cin} input channels, got {cin}")
+        oshape = self.out_shape(x.shape)
+        if out is None:
+            out = torch.empty(oshape, dtype=torch.float32, device=x.device)
+        if in_scale is not None:
+            in_scale = _dev_f32(in_scale, "in_scale")
+            if in_scale.numel() != b * d * h * w:
+                raise RuntimeError("in_scale must be [B,D,H,W]")
+        if residual is not None:
+            residual = _dev_f32(residual, "residual")
+            if tuple(residual.shape) != tuple(oshape):
+                raise RuntimeError("residual shape mismatch")
+        lib = _lib.load()
+        with torch.cuda.device(x.device):
+            _lib.check(lib.dv_conv3d_f32(x.data_ptr(), self.wpacked.data_ptr(), _lib.ptr(self.scale),
+                                         _lib.ptr(self.shift), _lib.ptr(in_scale), _lib.ptr(residual),
+                                         out.data_ptr(), b, cin, d, h, w, self.cout, self.k,
+                                         self.stride, self.act, _lib.stream_ptr()), "dv_conv3d_f32")
+        return out
+
+
+class Deconv3dPlan:
+    """ConvTranspose3d(k=3, s=2, p=1, output_padding=1, bias=False) + BatchNorm3d (eval)
+    + skip add + activation (acv_ddim.py:74-80, :91-92)."""
+
+    def __init__(self, weight: torch.Tensor, bn: Optional[Tuple[torch.Tensor, ...]] = None,
+                 act: int = ACT_NONE, eps: float = 1e-5):
+        w = _dev_f32(weight.detach(), "weight")
+        self.cin, self.cout = w.shape[0], w.shape[1]
+        if tuple(w.shape[2:]) != (3, 3, 3):
+            raise _lib.DiffuVolumeError("only the k3 s2 p1 op1 transposed convolution is implemented")
+        self.act = act
+        lib = _lib.load()
+        n = lib.dv_deconv3d_packed_floats(self.cin, self.cout)
+        self.wpacked = torch.empty(n, dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            _lib.check(lib.dv_deconv3d_pack_weights_f32(w.data_ptr(), self.wpacked.data_ptr(), self.cin,
+                                                        self.cout, _lib.stream_ptr()),
+                       "dv_deconv3d_pack_weights_f32")
+        self.scale, self.shift = _fold_bn(bn, None, self.cout, w.device, eps)
+
+    def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        x = _dev_f32(x, "x")
+        b, cin, d, h, w = x.shape
+        if cin != self.cin:
+            raise RuntimeError(f"expected {self.cin} input channels, got {cin}")
+        out = torch.empty((b, self.cout, 2 * d, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+        if residual is not None:
+            residual = _dev_f32(residual, "residual")
+            if tuple(residual.shape) != tuple(out.shape):
+                raise RuntimeError("residual shape mismatch")
+        lib = _lib.load()
+        with torch.cuda.device(x.device):
+            _lib.check(lib.dv_deconv3d_k3s2_f32(x.data_ptr(), self.wpacked.data_ptr(), _lib.ptr(self.scale),
+                                                _lib.ptr(self.shift), _lib.ptr(residual), out.data_ptr(),
+                                                b, cin, d, h, w, self.cout, self.act, _lib.stream_ptr()),
+                       "dv_deconv3d_k3s2_f32")
+        return out
+
+
+def _fold_bn(bn, bias, cout, device, eps):
+    """Eval-mode BatchNorm -> per-channel (scale, shift); a conv bias folds into shift."""
+    if bn is None and bias is None:
+        return None, None
+    if bn is None:
+        return None, bias.detach().to(device=device, dtype=torch.float32).contiguous()
+    gamma, beta, mean, var = (t.detach().to(device=device, dtype=torch.float32) for t in bn)
+    scale = gamma / torch.sqrt(var + eps)
+    shift = beta - mean * scale
+    if bias is not None:
+        shift = shift + bias.detach().to(device=device, dtype=torch.float32) * scale
+    return scale.contiguous(), shift.contiguous()
+
+
+def window_attention(x: torch.Tensor, qkv_w: torch.Tensor, qkv_b: torch.Tensor, proj_w: torch.Tensor,
+                     proj_b: torch.Tensor, heads: int = 16) -> torch.Tensor:
+    """attention_block.forward (submodule.py:398-429) on [B,C,D,H,W]."""
+    x = _dev_f32(x, "x")
+    b, c, d, h, w = x.shape
+    qkv_w = _dev_f32(qkv_w.detach(), "qkv_w")
+    qkv_b = _dev_f32(qkv_b.detach(), "qkv_b")
+    proj_w = _dev_f32(proj_w.detach().reshape(c, c), "proj_w")
+    proj_b = _dev_f32(proj_b.detach(), "proj_b")
+    out = torch.empty_like(x)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.dv_window_attn3d_f32(x.data_ptr(), qkv_w.data_ptr(), qkv_b.data_ptr(),
+                                            proj_w.data_ptr(), proj_b.data_ptr(), out.data_ptr(),
+                                            b, c, d, h, w, heads, _lib.stream_ptr()),
+                   "dv_window_attn3d_f32")
+    return out

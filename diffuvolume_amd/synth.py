@@ -1,0 +1,114 @@
+"""Deterministic synthetic weights and stereo inputs (no checkpoints or datasets ship with
+the reference: README.md:8, .MISSING_LARGE_BLOBS).  Every tensor is drawn from its own
+CPU generator seeded by crc32(key) ^ seed, so the values depend only on (seed, key, shape)
+-- not on module construction order -- and are identical here and on the GPU box.  Used by
+oracle/make_golden.py (loaded into the imported reference), the tests and bench.py."""
+from __future__ import annotations
+
+import math
+import zlib
+from typing import Dict, Mapping
+
+import torch
+
+
+def _gen(seed: int, key: str) -> torch.Generator:
+    g = torch.Generator(device="cpu")
+    g.manual_seed((zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
+    return g
+
+
+def synth_state_dict(template: Mapping[str, torch.Tensor], seed: int = 0,
+                     logit_gain: float = 1.0) -> Dict[str, torch.Tensor]:
+    """Random but well-conditioned values for every entry of ``template`` (a state_dict):
+    conv weights ~ N(0, sqrt(2/(k^3*Cout))) as the reference initialises them
+    (acv_ddim.py:224-238), BatchNorm with NON-trivial affine and running statistics,
+    xavier-uniform Linear weights.  float64 schedule buffers are kept.  ``logit_gain``
+    scales the single-channel classifier heads (sharper or flatter softmax)."""
+    keys = set(template.keys())
+    out: Dict[str, torch.Tensor] = {}
+    for key, ref in template.items():
+        g = _gen(seed, key)
+        shape = tuple(ref.shape)
+        leaf = key.rsplit(".", 1)[-1]
+        stem = key.rsplit(".", 1)[0]
+        is_bn = (stem + ".running_mean") in keys
+        if ref.dtype == torch.float64 or not ref.dtype.is_floating_point:
+            out[key] = ref.clone()                       # schedule buffers, num_batches_tracked
+        elif leaf == "running_mean":
+            out[key] = torch.randn(shape, generator=g) * 0.1
+        elif leaf == "running_var":
+            out[key] = torch.rand(shape, generator=g) + 0.5
+        elif is_bn and leaf == "weight":
+            out[key] = torch.rand(shape, generator=g) * 0.4 + 0.8
+        elif is_bn and leaf == "bias":
+            out[key] = torch.randn(shape, generator=g) * 0.1
+        elif leaf == "weight" and ref.dim() >= 3:        # Conv2d / Conv3d / ConvTranspose3d
+            kprod = 1
+            for s in shape[2:]:
+                kprod *= s
+            std = math.sqrt(2.0 / (kprod * shape[0]))
+            w = torch.randn(shape, generator=g) * std
+            if shape[0] == 1 and ref.dim() == 5:
+                w = w * logit_gain
+            out[key] = w
+        elif leaf == "weight" and ref.dim() == 2:        # Linear
+            a = math.sqrt(6.0 / (shape[0] + shape[1]))
+            out[key] = (torch.rand(shape, generator=g) * 2 - 1) * a
+        elif leaf == "bias":
+            out[key] = torch.randn(shape, generator=g) * 0.02
+        else:
+            out[key] = torch.randn(shape, generator=g) * 0.1
+        out[key] = out[key].to(ref.dtype)
+    return out
+
+
+def synth_features(b: int, c: int, h: int, w: int, seed: int, shifts=(6, 24, 60)) -> Dict[str, torch.Tensor]:
+    """Left/right feature maps with a real correlation ridge: right = left shifted by a
+    per-image disparity (in feature pixels) plus noise."""
+    g = _gen(seed, f"features{b}x{c}x{h}x{w}")
+    left = torch.randn(b, c, h, w, generator=g)
+    right = torch.empty_like(left)
+    for i in range(b):
+        d = shifts[i % len(shifts)] // 4 if w > 16 else 1
+        right[i] = torch.roll(left[i], shifts=-d, dims=-1)
+    right = right + 0.05 * torch.randn(b, c, h, w, generator=g)
+    return {"left": left, "right": right}
+
+
+def synth_stereo_batch(b: int, h: int, w: int, seed: int = 0, shifts=(6, 24, 60)) -> Dict[str, torch.Tensor]:
+    """left = randn, right = left rolled by d0 px + noise, gt = d0 + randn clamped
+    to (0,192), used = gt + 0.5 randn (stand-in for the origin network), disp = bilinear/4."""
+    import torch.nn.functional as F
+    g = _gen(seed, f"stereo{b}x{h}x{w}")
+    left = torch.randn(b, 3, h, w, generator=g)
+    right = torch.empty_like(left)
+    gt = torch.empty(b, h, w)
+    for i in range(b):
+        d0 = shifts[i % len(shifts)]
+        right[i] = torch.roll(left[i], shifts=-d0, dims=-1)
+        gt[i] = d0 + torch.randn(h, w, generator=g)
+    right = right + 0.05 * torch.randn(b, 3, h, w, generator=g)
+    gt = gt.clamp(0.5, 191.0)
+    used = (gt + 0.5 * torch.randn(b, h, w, generator=g)).clamp(0.0, 191.0)
+    disp = F.interpolate(used.clamp(0, 191).unsqueeze(1), size=(h // 4, w // 4), mode="bilinear") / 4
+    return {"left": left, "right": right, "gt": gt, "used": used, "disp": disp}
+
+
+class NoiseTape:
+    """Deterministic replacement for the DDIM loop's random draws (acv_ddim.py:354 'eps' =
+    randn_like(img), :360 'fill' = rand_like): the k-th draw of each kind comes from its own
+    seeded CPU generator in float64 and is cast to the requested dtype, so the reference
+    (patched torch.randn_like / rand_like), the CPU oracle and the HIP path all see the same
+    numbers whatever their device."""
+
+    def __init__(self, seed: int):
+        self.seed = seed
+        self.count = {"eps": 0, "fill": 0}
+
+    def __call__(self, kind: str, shape, dtype) -> torch.Tensor:
+        k = self.count[kind]
+        self.count[kind] = k + 1
+        g = _gen(self.seed, f"{kind}{k}")
+        fn = torch.randn if kind == "eps" else torch.rand
+        return fn(tuple(shape), generator=g, dtype=torch.float64).to(dtype)

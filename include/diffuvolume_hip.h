@@ -1,0 +1,163 @@
+/* diffuvolume_hip.h -- C ABI of libdiffuvolume_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (iSEE-Laboratory/DiffuVolume) has no FFI layer: its hot path is
+ * Python calling ATen.  This header is the boundary a maintainer binds instead
+ * (ctypes stub in INTEGRATION.md).  Each entry point names the reference code it
+ * replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to a dense, contiguous row-major tensor in
+ *    the reference's own layout (NCHW / NCDHW); outputs are caller-allocated;
+ *  - nothing here allocates, frees, synchronises or keeps global mutable state;
+ *    calls are re-entrant and are enqueued on `stream` of the current device;
+ *  - return value: 0 = ok, <0 = DV_ERR_* (bad argument), >0 = hipError_t.
+ */
+#ifndef DIFFUVOLUME_HIP_H
+#define DIFFUVOLUME_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dv_stream_t; /* hipStream_t */
+
+#define DV_OK 0
+#define DV_ERR_NULL (-1)        /* required pointer is NULL */
+#define DV_ERR_SHAPE (-2)       /* dimension <= 0 or inconsistent */
+#define DV_ERR_UNSUPPORTED (-3) /* shape/option outside what the kernels implement */
+#define DV_ERR_ALIGN (-4)       /* pointer not 16-byte aligned */
+
+#define DV_ACT_NONE 0
+#define DV_ACT_RELU 1      /* SceneFlow / ACVNet */
+#define DV_ACT_MISH 2      /* KITTI12 / PCWNet: x*tanh(softplus(x)) */
+#define DV_ACT_LEAKY 3     /* KITTI15 / IGEV: LeakyReLU(0.01) */
+
+int dv_version(void);
+const char* dv_error_string(int code);
+
+/* ---- cost-volume builders ------------------------------------------------
+ * build_gwc_volume: SceneFlow/models/submodule.py:228-238 (+ groupwise_correlation
+ * :209-215); identical in KITTI12 :109-119 and KITTI15 :159-169.
+ * ref,tgt [B,C,H,W] -> out [B,G,D,H,W];  out[b,g,d,y,x] = mean_c ref*tgt(x-d), 0 for x<d. */
+int dv_gwc_volume_f32(const float* ref, const float* tgt, float* out,
+                      int B, int C, int H, int W, int D, int G, dv_stream_t stream);
+
+/* build_concat_volume: SceneFlow/models/submodule.py:180-191 (zero_left=0, = KITTI15
+ * :206-217) and KITTI12/models/submodule.py:86-97 (zero_left=1).
+ * ref,tgt [B,C,H,W] -> out [B,2C,D,H,W]. */
+int dv_concat_volume_f32(const float* ref, const float* tgt, float* out,
+                         int B, int C, int H, int W, int D, int zero_left, dv_stream_t stream);
+
+/* F.softmax(att_weights, dim=2) * build_concat_volume(...): SceneFlow/models/acv_ddim.py:388-390
+ * fused.  att [B,1,D,H,W] logits -> out [B,2C,D,H,W]. */
+int dv_concat_attn_volume_f32(const float* ref, const float* tgt, const float* att, float* out,
+                              int B, int C, int H, int W, int D, dv_stream_t stream);
+
+/* ---- time-shifted noise -> [0,1] volume filter ----------------------------
+ * DynamicHead add (SceneFlow/models/head.py:74-77) + clamp + rescale
+ * (acv_ddim.py:256-258).  x_t [B,C,HW], shift [B,C] (fp32, the MLP output),
+ * n01 = (clamp(x_t+shift,-1,1)+1)/2 in the state dtype; n01_f32 = (float)n01
+ * is what multiplies the volume (acv_ddim.py:260).  The f32 flavour is the
+ * first DDIM step (state still fp32), f64 the later ones. */
+int dv_noise_prepare_f32(const float* x_t, const float* shift, float* n01,
+                         int B, int C, int HW, dv_stream_t stream);
+int dv_noise_prepare_f64(const double* x_t, const float* shift, double* n01, float* n01_f32,
+                         int B, int C, int HW, dv_stream_t stream);
+
+/* ---- 3-D aggregation convolutions ------------------------------------------
+ * convbn_3d (+ReLU/Mish/LeakyReLU): SceneFlow/models/submodule.py:94-97 and its
+ * uses acv_ddim.py:60-70,:82-83,:200-222.  Cubic kernel k in {1,3}, pad (k-1)/2,
+ * stride in {1,2}; implicit GEMM on v_mfma_f32_16x16x4_f32 (exact fp32).
+ *   y = act( conv(in * in_scale) * ch_scale[co] + ch_bias[co] + residual )
+ * in [B,Cin,D,H,W]; in_scale [B,D,H,W] or NULL (the `volume * noise.unsqueeze(1)`
+ * prologue of acv_ddim.py:260); ch_scale/ch_bias [Cout] or NULL (eval-mode BN
+ * folded by the caller); residual [B,Cout,Do,Ho,Wo] or NULL; out same shape.
+ * `wpacked` comes from dv_conv3d_pack_weights_f32. */
+size_t dv_conv3d_packed_floats(int Cin, int Cout, int k);
+int dv_conv3d_pack_weights_f32(const float* w /*[Cout,Cin,k,k,k]*/, float* wpacked,
+                               int Cin, int Cout, int k, dv_stream_t stream);
+int dv_conv3d_f32(const float* in, const float* wpacked, const float* ch_scale, const float* ch_bias,
+                  const float* in_scale, const float* residual, float* out,
+                  int B, int Cin, int D, int H, int W, int Cout, int k, int stride, int act,
+                  dv_stream_t stream);
+
+/* nn.ConvTranspose3d(k=3, stride=2, padding=1, output_padding=1, bias=False) + BN
+ * + skip add + activation: acv_ddim.py:74-80 and :91-92.  w [Cin,Cout,3,3,3].
+ * in [B,Cin,D,H,W] -> out [B,Cout,2D,2H,2W]. */
+size_t dv_deconv3d_packed_floats(int Cin, int Cout);
+int dv_deconv3d_pack_weights_f32(const float* w /*[Cin,Cout,3,3,3]*/, float* wpacked,
+                                 int Cin, int Cout, dv_stream_t stream);
+int dv_deconv3d_k3s2_f32(const float* in, const float* wpacked, const float* ch_scale,
+                         const float* ch_bias, const float* residual, float* out,
+                         int B, int Cin, int D, int H, int W, int Cout, int act, dv_stream_t stream);
+
+/* attention_block.forward: SceneFlow/models/submodule.py:398-429 -- 4x4x4 window
+ * multi-head self-attention (heads x C/heads), qkv Linear(C,3C)+bias, softmax,
+ * final 1x1x1 Conv3d(C,C)+bias.  x [B,C,D,H,W] -> out same shape.  D must be a
+ * multiple of 4; H,W not multiples of 4 are zero-padded with the reference's
+ * -1000 mask rule.  C == 128, heads == 16 in every reference use. */
+int dv_window_attn3d_f32(const float* x, const float* qkv_w /*[3C,C]*/, const float* qkv_b /*[3C]*/,
+                         const float* proj_w /*[C,C]*/, const float* proj_b /*[C]*/, float* out,
+                         int B, int C, int D, int H, int W, int heads, dv_stream_t stream);
+
+/* ---- regression tail ---------------------------------------------------------
+ * F.upsample(trilinear, x4) + F.softmax(dim=1) + disparity_regression
+ * (acv_ddim.py:267-270, submodule.py:173-177) and the uncertainty
+ * sum_k |disp-k| p_k (acv_ddim.py:325-329), fused: the [B,4D,4h,4w] volumes are
+ * never materialised.  cost [B,D,h,w] -> disp [B,4h,4w], unc [B,4h,4w] (or NULL).
+ * align_corners: 0 = SceneFlow, 1 = KITTI12 (pwcnet_ddim.py:480). */
+int dv_upsample_softmax_regress_f32(const float* cost, float* disp, float* unc,
+                                    int B, int D, int h, int w, int align_corners, dv_stream_t stream);
+
+/* disparity_regression on a materialised probability volume (submodule.py:173-177):
+ * prob [B,D,H,W] -> disp [B,H,W]. */
+int dv_disparity_regression_f32(const float* prob, float* disp, int B, int D, int H, int W,
+                                dv_stream_t stream);
+
+/* two-hot encoding of a quarter-resolution disparity (acv_ddim.py:403-419):
+ * disp_q [B,h*w] -> x [B,nbins,h*w] = 2*twohot-1. */
+int dv_encode_two_hot_f32(const float* disp_q, float* x, int B, int nbins, int hw, dv_stream_t stream);
+
+/* One DDIM state update, everything after the regression of one step
+ * (acv_ddim.py:272-294 and :318-362):
+ *   x_start  = 2*twohot(bilinear_down4(clamp(disp,0,4*nbins-1))/4) - 1          (fp32 out)
+ *   pred_eps = (sqrt_recip*n01 - x_start) / sqrt_recipm1                          (fp64)
+ *   keep     = bilinear_down4( |disp-used|<dif_thr & unc<unc_thr );  mask = clamp(mask+keep,0,1)
+ *   x_next   = last ? x_start : (mask==0 ? fill : x_start*sqrt_alpha_next + c*pred_eps + sigma*eps)
+ *   ens     += cof * disp
+ * n01_f32 / n01_f64: exactly one is non-NULL (state dtype of this step).
+ * eps_f32 / eps_f64: exactly one non-NULL unless last (randn_like(img) follows img's dtype).
+ * disp,unc,used,ens [B,4h,4w]; mask [B,h,w] in/out; fill,x_next,pred_eps fp64 [B,nbins,h,w];
+ * pred_eps and ens may be NULL (not wanted). */
+typedef struct dv_ddim_coef {
+  double sqrt_recip_alpha;   /* sqrt(1/abar_t)     acv_ddim.py:156 */
+  double sqrt_recipm1_alpha; /* sqrt(1/abar_t - 1) acv_ddim.py:157 */
+  double sqrt_alpha_next;    /* sqrt(abar_next)    acv_ddim.py:356 */
+  double c;                  /* sqrt(1-abar_next-sigma^2) acv_ddim.py:352 */
+  double sigma;              /* acv_ddim.py:351 */
+  float dif_thr;             /* 1  (acv_ddim.py:323) */
+  float unc_thr;             /* 3  (acv_ddim.py:330) */
+  float cof;                 /* ensemble weight of this step's disparity (acv_ddim.py:367) */
+  int last;                  /* time_next < 0 (acv_ddim.py:344-346) */
+} dv_ddim_coef;
+
+int dv_ddim_step(const float* disp, const float* unc, const float* used,
+                 const float* n01_f32, const double* n01_f64,
+                 const float* eps_f32, const double* eps_f64, const double* fill,
+                 float* mask, float* x_start, double* pred_eps, double* x_next, float* ens,
+                 int B, int nbins, int h, int w, const dv_ddim_coef* coef, dv_stream_t stream);
+
+/* ---- metrics (SceneFlow/utils/metrics.py:22-65) -------------------------------
+ * Per-image sums over pixels with mask!=0: sums[b] = { n_mask, n_gt_pos, sum|gt-est|,
+ * n_D1 (err>3 & err/|gt|>0.05), n_err>1, n_err>2, n_err>3, 0 } as fp64 [B,8].
+ * The <0.1 mask-ratio skip and the means are taken by the caller. */
+int dv_masked_metrics_f32(const float* est, const float* gt, const uint8_t* mask, double* sums,
+                          int B, int HW, dv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFUVOLUME_HIP_H */

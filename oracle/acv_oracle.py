@@ -1,0 +1,350 @@
+"""CPU oracle for the DiffuVolume hot path (ACVNet + DDIM volume filter).
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``diffuvolume_amd/`` may import this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` do, and only as the checker / the timed CPU baseline.
+
+This is a functional, plain-PyTorch (CPU, fp32 / fp64 exactly where the
+reference promotes) restatement of the reference algorithm.  It takes a flat
+``state_dict`` (reference key names) instead of ``nn.Module`` objects.  Every
+function cites the reference lines it follows (paths relative to the
+reference checkout).
+
+Parity pinning: the reference ships no tests or golden vectors, so the oracle
+is pinned against outputs of the reference itself, imported in the build
+container by ``oracle/make_golden.py``; the vectors live in ``tests/golden``
+and ``tests/test_oracle_golden.py`` checks every function here against them.
+Dataset-level EPE (0.46 px, README) is *unpinned*: no weights / data exist.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+
+
+# --------------------------------------------------------------------------
+# L1 ops: cost-volume builders and regression
+# --------------------------------------------------------------------------
+def groupwise_correlation(fea1: Tensor, fea2: Tensor, num_groups: int) -> Tensor:
+    """SceneFlow/models/submodule.py:209-215."""
+    b, c, h, w = fea1.shape
+    if c % num_groups != 0:
+        raise AssertionError("channels must divide into groups")
+    return (fea1 * fea2).view(b, num_groups, c // num_groups, h, w).mean(dim=2)
+
+
+def build_gwc_volume(ref: Tensor, tgt: Tensor, maxdisp: int, num_groups: int) -> Tensor:
+    """SceneFlow/models/submodule.py:228-238 (= KITTI12 :109-119, KITTI15 :159-169).
+
+    out[b,g,d,y,x] = mean_c ref[b,g*cpg+c,y,x] * tgt[b,g*cpg+c,y,x-d]  (0 for x<d)
+    """
+    b, c, h, w = ref.shape
+    vol = ref.new_zeros(b, num_groups, maxdisp, h, w)
+    for d in range(maxdisp):
+        if d >= w:
+            break
+        vol[:, :, d, :, d:] = groupwise_correlation(ref[..., d:], tgt[..., : w - d], num_groups)
+    return vol
+
+
+def build_concat_volume(ref: Tensor, tgt: Tensor, maxdisp: int, zero_left: bool = False) -> Tensor:
+    """SceneFlow/models/submodule.py:180-191 (zero_left=False; same as KITTI15 :206-217)
+    and KITTI12/models/submodule.py:86-97 (zero_left=True: the reference half is
+    also zero where x<d)."""
+    b, c, h, w = ref.shape
+    vol = ref.new_zeros(b, 2 * c, maxdisp, h, w)
+    for d in range(maxdisp):
+        if d >= w:
+            if not zero_left:
+                vol[:, :c, d] = ref
+            continue
+        if zero_left:
+            vol[:, :c, d, :, d:] = ref[..., d:]
+        else:
+            vol[:, :c, d] = ref
+        vol[:, c:, d, :, d:] = tgt[..., : w - d]
+    return vol
+
+
+def disparity_regression(prob: Tensor, maxdisp: int, keepdim: bool = False) -> Tensor:
+    """SceneFlow/models/submodule.py:173-177 (keepdim=True: KITTI15 :219-223)."""
+    if prob.dim() != 4:
+        raise AssertionError("expected [B,D,H,W]")
+    values = torch.arange(0, maxdisp, dtype=prob.dtype, device=prob.device).view(1, maxdisp, 1, 1)
+    return torch.sum(prob * values, 1, keepdim=keepdim)
+
+
+def attention_concat_volume(att: Tensor, concat: Tensor) -> Tensor:
+    """SceneFlow/models/acv_ddim.py:390 -- softmax over D of the attention logits
+    times the concat volume."""
+    return F.softmax(att, dim=2) * concat
+
+
+# --------------------------------------------------------------------------
+# conv helpers (eval-mode BN, exactly as nn.Sequential(Conv3d, BatchNorm3d))
+# --------------------------------------------------------------------------
+def _bn(x: Tensor, sd: SD, p: str) -> Tensor:
+    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"],
+                        sd[p + ".weight"], sd[p + ".bias"], False, 0.0, 1e-5)
+
+
+def convbn_3d(x: Tensor, sd: SD, p: str, stride: int, pad: int) -> Tensor:
+    """SceneFlow/models/submodule.py:94-97: Conv3d(bias=False) then BatchNorm3d
+    (keys ``p.0.weight`` and ``p.1.*``)."""
+    return _bn(F.conv3d(x, sd[p + ".0.weight"], None, stride, pad), sd, p + ".1")
+
+
+def attention_block(x: Tensor, sd: SD, p: str, heads: int = 16,
+                    block: Tuple[int, int, int] = (4, 4, 4)) -> Tensor:
+    """SceneFlow/models/submodule.py:398-429, restated per window.
+
+    Tokens of one (bd,bh,bw) window attend to each other; channel c = head*hd+dim.
+    H/W are zero-padded to multiples of the block; padded tokens are separated
+    from real ones with a -1000 additive mask (with the reference's quirk that
+    a zero bottom pad with a non-zero right pad marks *every* row, :414-416).
+    """
+    b, c, d0, h0, w0 = x.shape
+    bd, bh, bw = block
+    pad_r = (bw - w0 % bw) % bw
+    pad_b = (bh - h0 % bh) % bh
+    x = F.pad(x, (0, pad_r, 0, pad_b))
+    _, _, d, h, w = x.shape
+    nd, nh, nw = d // bd, h // bh, w // bw
+    hd = c // heads
+    # tokens [B, nd, nh, nw, bd*bh*bw, C]
+    tok = x.view(b, c, nd, bd, nh, bh, nw, bw).permute(0, 2, 4, 6, 3, 5, 7, 1)
+    tok = tok.reshape(b, nd * nh * nw, bd * bh * bw, c)
+    qkv = F.linear(tok, sd[p + ".qkv_3d.weight"], sd[p + ".qkv_3d.bias"])
+    qkv = qkv.view(b, nd * nh * nw, bd * bh * bw, 3, heads, hd)
+    q = qkv[..., 0, :, :].permute(0, 1, 3, 2, 4)   # [B, win, heads, tok, hd]
+    k = qkv[..., 1, :, :].permute(0, 1, 3, 2, 4)
+    v = qkv[..., 2, :, :].permute(0, 1, 3, 2, 4)
+    attn = (q @ k.transpose(-2, -1)) * (hd ** -0.5)
+    if pad_r > 0 or pad_b > 0:
+        m = torch.zeros(1, h, w)
+        m[:, h - pad_b if pad_b > 0 else 0:, :] = 1      # -0: slice == whole axis (reference quirk)
+        m[:, :, w - pad_r if pad_r > 0 else 0:] = 1
+        m = m.view(1, nh, bh, nw, bw).transpose(2, 3).reshape(1, nh * nw, bh * bw)
+        am = m.unsqueeze(2) - m.unsqueeze(3)
+        am = torch.where(am != 0, torch.full_like(am, -1000.0), torch.zeros_like(am))
+        am = am.repeat(1, nd, bd, bd).unsqueeze(2)          # [1, win, 1, tok, tok]
+        attn = attn + am
+    attn = torch.softmax(attn, dim=-1)
+    out = attn @ v                                           # [B, win, heads, tok, hd]
+    out = out.view(b, nd, nh, nw, heads, bd, bh, bw, hd).permute(0, 4, 8, 1, 5, 2, 6, 3, 7)
+    out = out.reshape(b, c, d, h, w)
+    if pad_r > 0 or pad_b > 0:
+        out = out[:, :, :, :h0, :w0]
+    return F.conv3d(out, sd[p + ".final1x1.weight"], sd[p + ".final1x1.bias"])
+
+
+def hourglass(x: Tensor, sd: SD, p: str) -> Tensor:
+    """SceneFlow/models/acv_ddim.py:56-93."""
+    c1 = F.relu(convbn_3d(x, sd, p + ".conv1.0", 2, 1))
+    c2 = F.relu(convbn_3d(c1, sd, p + ".conv2.0", 1, 1))
+    c3 = F.relu(convbn_3d(c2, sd, p + ".conv3.0", 2, 1))
+    c4 = F.relu(convbn_3d(c3, sd, p + ".conv4.0", 1, 1))
+    c4 = attention_block(c4, sd, p + ".attention_block")
+    up5 = _bn(F.conv_transpose3d(c4, sd[p + ".conv5.0.weight"], None, 2, 1, 1), sd, p + ".conv5.1")
+    c5 = F.relu(up5 + convbn_3d(c2, sd, p + ".redir2", 1, 0))
+    up6 = _bn(F.conv_transpose3d(c5, sd[p + ".conv6.0.weight"], None, 2, 1, 1), sd, p + ".conv6.1")
+    return F.relu(up6 + convbn_3d(x, sd, p + ".redir1", 1, 0))
+
+
+def conv_relu_conv(x: Tensor, sd: SD, p: str, relu_last: bool, bn_last: bool = True) -> Tensor:
+    """The ``nn.Sequential(convbn_3d, ReLU, convbn_3d | Conv3d[, ReLU])`` stacks of
+    acv_ddim.py:200-222 (dres0 / dres1 / classif*)."""
+    y = F.relu(convbn_3d(x, sd, p + ".0", 1, 1))
+    if bn_last:
+        y = convbn_3d(y, sd, p + ".2", 1, 1)
+    else:
+        y = F.conv3d(y, sd[p + ".2.weight"], None, 1, 1)
+    return F.relu(y) if relu_last else y
+
+
+# --------------------------------------------------------------------------
+# time embedding + diffusion schedule
+# --------------------------------------------------------------------------
+def time_shift(t: Tensor, sd: SD, p: str = "time_embedding", d_model: int = 48) -> Tensor:
+    """SceneFlow/models/head.py:22-34 and :74-75: sinusoidal(d_model) -> Linear ->
+    GELU -> Linear -> SiLU -> Linear; returns the per-(batch, channel) shift."""
+    half = d_model // 2
+    freq = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1)))
+    emb = t[:, None] * freq[None, :]
+    emb = torch.cat((emb.sin(), emb.cos()), dim=-1)
+    y = F.linear(emb, sd[p + ".time_mlp.1.weight"], sd[p + ".time_mlp.1.bias"])
+    y = F.linear(F.gelu(y), sd[p + ".time_mlp.3.weight"], sd[p + ".time_mlp.3.bias"])
+    return F.linear(F.silu(y), sd[p + ".block_time_mlp.1.weight"], sd[p + ".block_time_mlp.1.bias"])
+
+
+def cosine_alphas_cumprod(timesteps: int = 1000, s: float = 0.008) -> Tensor:
+    """SceneFlow/models/acv_ddim.py:113-119 and :134-136 (float64 throughout)."""
+    x = torch.linspace(0, timesteps, timesteps + 1, dtype=torch.float64)
+    ac = torch.cos(((x / timesteps) + s) / (1 + s) * math.pi * 0.5) ** 2
+    ac = ac / ac[0]
+    betas = torch.clip(1 - (ac[1:] / ac[:-1]), 0, 0.999)
+    return torch.cumprod(1.0 - betas, dim=0)
+
+
+def ddim_time_pairs(total: int, steps: int) -> List[Tuple[int, int]]:
+    """SceneFlow/models/acv_ddim.py:306-308."""
+    times = torch.linspace(-1, total - 1, steps=steps + 1)
+    times = list(reversed(times.int().tolist()))
+    return list(zip(times[:-1], times[1:]))
+
+
+def encode_two_hot(disp_q: Tensor, nbins: int = 48) -> Tensor:
+    """SceneFlow/models/acv_ddim.py:277-290 (and :403-414): quarter-res disparity
+    [B,1,h,w] (or [B,1,1,h,w]) -> two-hot distribution over ``nbins`` (values in
+    [0,1], before the *2-1 rescale).  Bin floor(d) gets 1-frac, the next bin
+    (clamped) gets frac; floor(d)==nbins-1 is forced to a pure last-bin one-hot."""
+    dq = disp_q.reshape(disp_q.shape[0], 1, disp_q.shape[-2], disp_q.shape[-1])
+    b, _, h, w = dq.shape
+    real = torch.floor(dq).long()
+    coff = real - dq + 1
+    vol = torch.zeros(b, nbins, h, w, dtype=torch.float32)
+    vol = vol.view(b, nbins, -1).scatter_(1, real.view(b, 1, -1), coff.view(b, 1, -1)).reshape(b, nbins, h, w)
+    vol = vol.view(b, nbins, -1).scatter_(1, torch.clamp(real + 1, 0, nbins - 1).view(b, 1, -1),
+                                          (1 - coff).view(b, 1, -1)).reshape(b, nbins, h, w)
+    last = torch.zeros(b, nbins, h, w, dtype=torch.float32)
+    last[:, -1] = 1
+    return torch.where(real == nbins - 1, last, vol)
+
+
+def upsample_softmax_regress(cost: Tensor, maxdisp: int, align_corners: bool = False
+                             ) -> Tuple[Tensor, Tensor]:
+    """SceneFlow/models/acv_ddim.py:267-270: trilinear x4 of the [B,1,D/4,h,w] cost
+    to [B,maxdisp,4h,4w], softmax over disparity, soft-argmax.  Returns
+    (disp [B,H,W], prob [B,maxdisp,H,W])."""
+    b, _, d, h, w = cost.shape
+    if align_corners:
+        up = F.interpolate(cost, [maxdisp, h * 4, w * 4], mode="trilinear", align_corners=True)
+    else:
+        up = F.interpolate(cost, [maxdisp, h * 4, w * 4], mode="trilinear")
+    prob = F.softmax(torch.squeeze(up, 1), dim=1)
+    return disparity_regression(prob, maxdisp), prob
+
+
+def disparity_uncertainty(disp: Tensor, prob: Tensor) -> Tensor:
+    """SceneFlow/models/acv_ddim.py:325-329: sum_k |disp - k| * p_k."""
+    k = torch.arange(0, prob.shape[1], dtype=disp.dtype).view(1, -1, 1, 1)
+    return torch.sum(torch.abs(disp.unsqueeze(1) - k) * prob, dim=1)
+
+
+# --------------------------------------------------------------------------
+# the per-step volume filter and the DDIM loop (ACV flavour)
+# --------------------------------------------------------------------------
+class ACVDiffusionOracle:
+    """Functional mirror of ``ACVNet_DDIM.model_predictions`` / ``ddim_sample``
+    (SceneFlow/models/acv_ddim.py:254-370) over a reference ``state_dict``."""
+
+    def __init__(self, sd: SD, maxdisp: int = 192, sampling_timesteps: int = 5,
+                 cof: Sequence[float] = (0.5, 0.0, 0.0, 0.0, 0.2, 0.3)):
+        self.sd = sd
+        self.maxdisp = maxdisp
+        self.scale = 1.0
+        self.num_timesteps = 1000
+        self.sampling_timesteps = sampling_timesteps
+        self.eta = 1.0
+        self.cof = tuple(cof)
+        ac = cosine_alphas_cumprod(self.num_timesteps)
+        self.alphas_cumprod = ac
+        self.sqrt_recip_alphas_cumprod = torch.sqrt(1.0 / ac)
+        self.sqrt_recipm1_alphas_cumprod = torch.sqrt(1.0 / ac - 1)
+
+    # acv_ddim.py:260-266
+    def aggregate(self, volume: Tensor) -> Tensor:
+        sd = self.sd
+        cost0 = conv_relu_conv(volume, sd, "dres0", relu_last=True)
+        cost0 = conv_relu_conv(cost0, sd, "dres1", relu_last=False) + cost0
+        out1 = hourglass(cost0, sd, "dres2")
+        out2 = hourglass(out1, sd, "dres3")
+        return conv_relu_conv(out2, sd, "classif2", relu_last=False, bn_last=False)
+
+    def noise_to_filter(self, x_t: Tensor, t: Tensor) -> Tensor:
+        """acv_ddim.py:256-258 (+ head.py:74-77): shift, clamp, map to [0,1].
+        dtype follows x_t (fp32 at the first step, fp64 afterwards)."""
+        shift = time_shift(t, self.sd)[:, :, None, None]
+        n = x_t + shift
+        n = torch.clamp(n, min=-1 * self.scale, max=self.scale)
+        return ((n / self.scale) + 1) / 2
+
+    def model_predictions(self, volume: Tensor, x_t: Tensor, t: Tensor):
+        """acv_ddim.py:254-296 -> (pred_noise f64, x_start f32, disp, prob)."""
+        n01 = self.noise_to_filter(x_t, t)
+        cost = self.aggregate(volume * n01.unsqueeze(1).float())
+        pred, prob = upsample_softmax_regress(cost, self.maxdisp)
+        dn = torch.clamp(pred, 0, self.maxdisp - 1).unsqueeze(1)
+        hh, ww = dn.shape[-2:]
+        dn = F.interpolate(dn, size=(hh // 4, ww // 4), mode="bilinear") / 4
+        x_start = encode_two_hot(dn, self.maxdisp // 4)
+        x_start = self.scale * (x_start * 2 - 1.0)
+        x_start = torch.clamp(x_start, min=-self.scale, max=self.scale)
+        bshape = (x_t.shape[0], 1, 1, 1)
+        # quirk kept: the [0,1] filter tensor, not x_t, enters here
+        pred_noise = ((self.sqrt_recip_alphas_cumprod.gather(-1, t).reshape(bshape) * n01 - x_start)
+                      / self.sqrt_recipm1_alphas_cumprod.gather(-1, t).reshape(bshape))
+        return pred_noise, x_start, pred, prob
+
+    def ddim_sample(self, volume: Tensor, used: Tensor, x_T: Tensor,
+                    draw: Callable[[str, Tuple[int, ...], torch.dtype], Tensor]):
+        """acv_ddim.py:298-370.  ``draw(kind, shape, dtype)`` supplies the random
+        tensors in reference order: per non-final step 'eps' (randn_like(img),
+        :354) then 'fill' (rand_like, :360).  Returns (final, stack [S+1,B,H,W])."""
+        b, _, _, h, w = volume.shape
+        img = x_T
+        final = [used.unsqueeze(0)]
+        mask = torch.zeros(b, h, w, dtype=torch.float32)
+        for time, time_next in ddim_time_pairs(self.num_timesteps, self.sampling_timesteps):
+            t = torch.full((b,), time, dtype=torch.long)
+            pred_noise, x_start, disp, prob = self.model_predictions(volume, img, t)
+            final.append(disp.unsqueeze(0))
+            dif = torch.abs(disp - used)
+            unc = disparity_uncertainty(disp, prob)
+            keep = ((dif < 1) & (unc < 3)).float()
+            keep = F.interpolate(keep.unsqueeze(1), size=(h, w), mode="bilinear").squeeze(1)
+            mask = torch.clamp(mask + keep, 0, 1)
+            if time_next < 0:
+                img = x_start
+                continue
+            alpha = self.alphas_cumprod[time]
+            alpha_next = self.alphas_cumprod[time_next]
+            sigma = self.eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+            c = (1 - alpha_next - sigma ** 2).sqrt()
+            eps = draw("eps", tuple(img.shape), img.dtype)
+            img = x_start * alpha_next.sqrt() + c * pred_noise + sigma * eps
+            fill = draw("fill", tuple(img.shape), torch.float64)
+            img = torch.where(mask.unsqueeze(1) == 0, fill, img)
+        stack = torch.cat(final, dim=0)
+        cof = torch.tensor(self.cof).view(-1, 1, 1, 1)
+        return torch.sum(stack * cof, dim=0), stack
+
+    def encode_x_T(self, disp_q: Tensor) -> Tensor:
+        """acv_ddim.py:403-419 (mask_gt is None at every call site)."""
+        return (encode_two_hot(disp_q, self.maxdisp // 4) * 2 - 1) * self.scale
+
+
+# --------------------------------------------------------------------------
+# metrics (SceneFlow/utils/metrics.py:22-65) as per-image sums
+# --------------------------------------------------------------------------
+def image_metrics(est: Tensor, gt: Tensor, mask: Tensor) -> Dict[str, Tensor]:
+    """Per-batch metric values with the reference's semantics: per-image masked
+    means, images whose mask ratio ``mask.mean()/(gt>0).mean()`` is <0.1 are
+    skipped, batch value = mean over kept images (0 if none)."""
+    out = {k: [] for k in ("EPE", "D1", "Thres1", "Thres2", "Thres3")}
+    for i in range(gt.shape[0]):
+        if mask[i].float().mean() / (gt[i] > 0).float().mean() < 0.1:
+            continue
+        e, g = est[i][mask[i]], gt[i][mask[i]]
+        err = torch.abs(g - e)
+        out["EPE"].append(F.l1_loss(e, g))
+        out["D1"].append(((err > 3) & (err / g.abs() > 0.05)).float().mean())
+        for n, thr in (("Thres1", 1.0), ("Thres2", 2.0), ("Thres3", 3.0)):
+            out[n].append((err > thr).float().mean())
+    return {k: (torch.stack(v).mean() if v else torch.tensor(0.0)) for k, v in out.items()}

@@ -1,0 +1,54 @@
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(name):
+    """tests/golden/<name>.npz -> dict of torch tensors (numpy scalars stay python numbers)."""
+    out = {}
+    with np.load(GOLDEN / f"{name}.npz", allow_pickle=False) as z:
+        for k in z.files:
+            a = z[k]
+            if a.dtype.kind in "US":
+                out[k] = a
+            elif a.ndim == 0:
+                out[k] = a.item()
+            else:
+                out[k] = torch.from_numpy(a.copy())
+    return out
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
+
+
+@pytest.fixture(scope="session")
+def acv_state_dict():
+    """The synthetic ACVNet_DDIM weights the golden vectors were produced with (seed 1, gain 8)."""
+    from diffuvolume_amd.acv_ddim import ACVNet_DDIM
+    from diffuvolume_amd.synth import synth_state_dict
+    return synth_state_dict(ACVNet_DDIM(192, False, False).state_dict(), seed=1, logit_gain=8.0)

@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- stereo pairs/s of the DiffuVolume hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 8] [--height 512] [--width 960]
+
+One "step" = one pass of the hot path (SURVEY 8d "HOT") over one batch of synthetic stereo
+pairs per GPU, inputs already resident in HBM:
+    build_gwc_volume (K1)  +  softmax(att) * build_concat_volume (K2)
+    + S DDIM steps x [ time-shift filter (K3) -> dres0/dres1/hourglass x2/classif2 (K4-K6)
+                       -> trilinear/softmax/regression (K7) -> two-hot + DDIM update (K8) ]
+    + masked EPE/D1 sums (K9);  one all-reduce of the metric sums after the K steps (RCCL).
+Workload = BASELINE.json configs[1]: SceneFlow ACVNet+DiffuVolume, 960x540 frames cropped to
+960x512 as the reference's loader does (sceneflow_dataset.py:60-65), maxdisp 192, batch 8 per
+GPU, 5 DDIM steps, fp32.  N>1: one process per GPU (torchrun), weak scaling.
+
+Prints ONE JSON line (rank 0): the driver contract plus `roofline` (dominant kernel: the
+fp32-MFMA implicit-GEMM conv, HIP-event timed inside the timed region) and `cpu_baseline`
+(the CPU oracle on a bounded sample of the same workload, rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+
+PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+ALGO_BYTES_PER_PAIR = 23.2e9      # ideal-fusion fp32 HBM bytes of HOT per pair (5 steps)
+ALGO_FLOP_PER_PAIR = 3.76e12
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8, help="stereo pairs per GPU")
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=960)
+    ap.add_argument("--ddim-steps", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    return ap.parse_args()
+
+
+def make_inputs(batch, h, w, seed, device):
+    """Synthetic quarter-resolution features with a real correlation ridge."""
+    from diffuvolume_amd.synth import _gen
+    g = _gen(seed, f"bench{batch}x{h}x{w}")
+    shifts = (6, 24, 60)
+
+    def pair(c):
+        left = torch.randn(batch, c, h, w, generator=g)
+        right = torch.stack([torch.roll(left[i], -(shifts[i % 3] // 4), dims=-1) for i in range(batch)])
+        return left, right + 0.05 * torch.randn(batch, c, h, w, generator=g)
+
+    fl, fr = pair(320)
+    cl, cr = pair(32)
+    att = torch.randn(batch, 1, 48, h, w, generator=g) * 2
+    gt = torch.stack([shifts[i % 3] + torch.randn(4 * h, 4 * w, generator=g) for i in range(batch)]).clamp(0.5, 191)
+    used = (gt + 0.5 * torch.randn(batch, 4 * h, 4 * w, generator=g)).clamp(0, 191)
+    dq = torch.nn.functional.interpolate(used.unsqueeze(1), size=(h, w), mode="bilinear") / 4
+    host = dict(fl=fl, fr=fr, cl=cl, cr=cr, att=att, gt=gt, used=used, dq=dq)
+    return host, {k: v.to(device) for k, v in host.items()}
+
+
+def hot_path(model, x, tape=None):
+    """One pass of the hot path; returns (final disparity, per-step stack, gwc volume)."""
+    import diffuvolume_amd as dv
+    gwc = dv.build_gwc_volume(x["fl"], x["fr"], 48, 40)
+    vol = dv.build_concat_attention_volume(x["cl"], x["cr"], x["att"], 48)
+    x_T = model.encode_disparity(x["dq"])
+    final, stack = model.ddim_sample(vol, x["used"], x_T, noise=tape)
+    return final, stack, gwc
+
+
+def cpu_baseline(sd, host, ddim_steps):
+    """The CPU oracle on a bounded sample: pair 0, both builders + ONE DDIM step at full size;
+    pairs/s extrapolated as 1 / (t_builders + S * t_step)."""
+    import torch.nn.functional as F
+    from oracle import acv_oracle as O
+    one = {k: v[:1].clone() for k, v in host.items()}
+    orc = O.ACVDiffusionOracle(sd)
+    t0 = time.perf_counter()
+    gwc = O.build_gwc_volume(one["fl"], one["fr"], 48, 40)
+    vol = O.attention_concat_volume(one["att"], O.build_concat_volume(one["cl"], one["cr"], 48))
+    x_T = orc.encode_x_T(one["dq"])
+    t1 = time.perf_counter()
+    t = torch.full((1,), 999, dtype=torch.long)
+    _, _, disp, prob = orc.model_predictions(vol, x_T, t)
+    O.disparity_uncertainty(disp, prob)
+    t2 = time.perf_counter()
+    del gwc, prob
+    tb, ts = t1 - t0, t2 - t1
+    return {"value": 1.0 / (tb + ddim_steps * ts), "unit": "pairs/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"oracle/acv_oracle.py, 1 pair 960x512: builders {tb:.2f} s + 1 of {ddim_steps} DDIM steps "
+                      f"{ts:.2f} s, extrapolated to {ddim_steps} steps",
+            "builders_s": tb, "ddim_step_s": ts}, disp
+
+
+def main():
+    a = parse()
+    from diffuvolume_amd import distributed as D
+    rank, world, local = D.init_from_env()
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU visible"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    import diffuvolume_amd as dv
+    from diffuvolume_amd import metrics as M
+    from diffuvolume_amd.profiling import KernelTimer
+    from diffuvolume_amd.synth import NoiseTape, synth_state_dict
+
+    h, w = a.height // 4, a.width // 4
+    cof = None if a.ddim_steps == 5 else tuple([0.5] + [0.0] * (a.ddim_steps - 1) + [0.5])
+    model = dv.ACVNet_DDIM(192, False, False, sampling_timesteps=a.ddim_steps, ensemble_cof=cof)
+    sd = synth_state_dict(model.state_dict(), seed=1, logit_gain=8.0)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(device).eval()
+    model.prepare()
+    host, x = make_inputs(a.batch, h, w, seed=100 + rank, device=device)
+    mask = (x["gt"] < 192) & (x["gt"] > 0)
+    acc = M.MetricAccumulator(device)
+
+    def step(tape=None):
+        final, stack, _ = hot_path(model, x, tape)
+        acc.update(M.batch_metrics(final, x["gt"], mask))
+        return final, stack
+
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            step()
+        acc = M.MetricAccumulator(device)
+        timer = None if a.no_kernel_timer else KernelTimer()
+        KernelTimer.active = timer
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        epe = acc.reduce()               # the one collective of the path (48-byte SUM over RCCL)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        dt = time.perf_counter() - t0
+        KernelTimer.active = None
+        dt = D.barrier_and_max(dt, device)
+
+    pairs = a.batch * world * a.steps
+    value = pairs / dt
+    out = {
+        "metric": "stereo pairs/sec, SceneFlow 960x540 (cropped 960x512) maxdisp=192, hot path",
+        "value": value, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"SceneFlow ACVNet+DiffuVolume hot path (gwc + concat*softmax(att) + "
+                               f"{a.ddim_steps} DDIM steps + EPE), {a.width}x{a.height}, maxdisp=192, "
+                               f"batch={a.batch}/GPU, random-init weights",
+                   "global_batch": a.batch * world, "ddim_steps": a.ddim_steps, "parallelism": f"dp{world}"},
+        "epe_px": epe["EPE"],
+        "hbm_roofline_frac_whole_path": value / world * ALGO_BYTES_PER_PAIR / (PEAK_HBM_GBS * 1e9),
+        "mfma_f32_roofline_frac_whole_path": value / world * ALGO_FLOP_PER_PAIR / (PEAK_MFMA_F32_TFLOPS * 1e12),
+    }
+    if rank == 0 and timer is not None:
+        ks = timer.summary()
+        dom = ks.get("conv3d_k3s1_co32")
+        if dom:
+            ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": None,
+                               "kernel": "conv3d_mfma_kernel (k3 s1 Cout=32: dres0/dres1/classif2 convs)",
+                               "launches": dom["launches"], "avg_ms": dom["avg_ms"],
+                               "algorithmic_gflop_per_launch": dom["flops"] / dom["launches"] / 1e9}
+        out["kernels_ms_per_step"] = {k: round(v["total_ms"] / a.steps, 3) for k, v in sorted(ks.items())}
+        out["kernels_tflops_or_gbs"] = {
+            k: (round(v["flops"] / v["total_ms"] / 1e9, 2) if k.startswith(("conv", "deconv", "window"))
+                else round(v["bytes"] / v["total_ms"] / 1e6, 1)) for k, v in sorted(ks.items())}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        base, disp_cpu = cpu_baseline(sd, host, a.ddim_steps)
+        out["cpu_baseline"] = base
+        with torch.no_grad():
+            one = {k: v[:1] for k, v in x.items()}
+            _, stack, _ = hot_path(model, one, NoiseTape(1))
+        d = (stack[1].cpu() - disp_cpu).abs()
+        out["parity_vs_oracle_step1"] = {"mean_abs_px": float(d.mean()), "frac_gt_1e-3": float((d > 1e-3).float().mean())}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

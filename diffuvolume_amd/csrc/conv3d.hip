@@ -14,6 +14,8 @@
 // (ds_read_b32, lanes contiguous along x), B = w_s[tap][cin][cout].  Several blocks are
 // resident per CU so one block's staging overlaps another's MFMA stream.
 // MFMA-bound: 27*Cin*2 flop per output float (AI 86-864 flop/byte at fp32).
+#include <cstdlib>
+
 #include "dv_common.h"
 
 namespace {
@@ -25,9 +27,10 @@ constexpr int round_mod(int v, int mod, int rem) {  // smallest v' >= v with v' 
   return r <= rem ? v + (rem - r) : v + (mod - r) + rem;
 }
 
-template <int KS_, int S_, int NT_, int MTX_, int TH_, int TD_, int KC_>
+template <int KS_, int S_, int NT_, int MTX_, int TH_, int TD_, int KC_, int WPS_>
 struct Geo {
   static constexpr int KS = KS_, S = S_, NT = NT_, MTX = MTX_, TH = TH_, TD = TD_, KC = KC_;
+  static constexpr int WPS = WPS_;  // resident waves per SIMD the register budget is sized for
   static constexpr int PAD = (KS - 1) / 2;
   static constexpr int T = KS * KS * KS;
   static constexpr int TW = MTX * 16;
@@ -60,8 +63,8 @@ struct ConvArgs {
   int vec_store;           // Wo % 4 == 0 and 16-byte aligned pointers
 };
 
-template <class G>
-__global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(ConvArgs a) {
+template <class G, bool HAS_SCALE>
+__global__ __launch_bounds__(256, G::WPS) void conv3d_mfma_kernel(ConvArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[G::IN_FLOATS + G::W_FLOATS];
   float* in_s = smem;
   float* w_s = smem + G::IN_FLOATS;
@@ -98,62 +101,93 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(ConvArgs a) {
   const size_t plane = (size_t)a.H * a.W;
   const size_t vol = (size_t)a.D * plane;
   const float* inb = a.in + (size_t)b * a.Cin * vol;
-  const float* scb = a.in_scale ? a.in_scale + (size_t)b * vol : nullptr;
+  const float* scb = (HAS_SCALE && a.in_scale) ? a.in_scale + (size_t)b * vol : nullptr;
 
+  // ---- staging plan: every thread owns NS spatial positions of the haloed brick (the same for
+  // every channel), so the index algebra and the bounds checks are done once per block ----
+  constexpr int NS = (G::PRAW + 255) / 256;
+  constexpr int ROWQ = G::COUT * 2 / 4;                   // float4 per (cinpair, tap) weight row
+  constexpr int NQ = (G::KC / 2) * G::T * ROWQ;           // float4 per weight chunk
+  constexpr int NWQ = (NQ + 255) / 256;
+  int sp[NS];       // offset inside one channel volume, -1 = zero padding
+  float scl[HAS_SCALE ? NS : 1];    // the `volume * noise` prologue factor of that position
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int r = tid + 256 * i;
+    const int zz = r / (G::IY * G::IX), r2 = r - zz * (G::IY * G::IX);
+    const int yy = r2 / G::IX, xx = r2 - yy * G::IX;
+    const int z = zi0 + zz, y = yi0 + yy, x = xi0 + xx;
+    const bool ok = r < G::PRAW && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H &&
+                    (unsigned)x < (unsigned)a.W;
+    sp[i] = ok ? (z * a.H + y) * a.W + x : -1;
+    if (HAS_SCALE) scl[i] = (ok && scb) ? scb[sp[i]] : 1.f;
+  }
+  float vin[G::KC][NS];
+  f32x4 vw[NWQ];
+  // global -> registers for one chunk of KC input channels (issued one chunk ahead of its use,
+  // so HBM/L2 latency hides behind the previous chunk's MFMA stream)
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int cl = 0; cl < G::KC; ++cl) {
+      const float* src = inb + (size_t)(c0 + cl) * vol;
+      const bool cok = (c0 + cl) < a.Cin;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) vin[cl][i] = (cok && sp[i] >= 0) ? src[sp[i]] : 0.f;
+    }
+    const float* wsrc = a.wpk + ((size_t)(c0 >> 1) * G::T * a.Coutp + co0) * 2;
+#pragma unroll
+    for (int q = 0; q < NWQ; ++q) {
+      const int e = tid + 256 * q;
+      const int row = e / ROWQ, qq = e - row * ROWQ;
+      if (e < NQ) vw[q] = reinterpret_cast<const f32x4*>(wsrc + (size_t)row * a.Coutp * 2)[qq];
+    }
+  };
+  auto commit = [&]() {  // registers -> LDS
+#pragma unroll
+    for (int cl = 0; cl < G::KC; ++cl)
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const int r = tid + 256 * i;
+        if (r < G::PRAW) in_s[cl * G::P + r] = HAS_SCALE ? vin[cl][i] * scl[i] : vin[cl][i];
+      }
+#pragma unroll
+    for (int q = 0; q < NWQ; ++q) {
+      const int e = tid + 256 * q;
+      if (e < NQ) reinterpret_cast<f32x4*>(w_s)[e] = vw[q];
+    }
+  };
+
+  fetch(0);
   for (int c0 = 0; c0 < a.Cin; c0 += G::KC) {
     __syncthreads();  // previous chunk's MFMAs are done reading LDS
-    // ---- stage the haloed input brick of KC channels ----
-#pragma unroll 4
-    for (int e = tid; e < G::KC * G::PRAW; e += 256) {
-      const int cl = e / G::PRAW, r = e - cl * G::PRAW;
-      const int zz = r / (G::IY * G::IX), r2 = r - zz * (G::IY * G::IX);
-      const int yy = r2 / G::IX, xx = r2 - yy * G::IX;
-      const int z = zi0 + zz, y = yi0 + yy, x = xi0 + xx, c = c0 + cl;
-      float v = 0.f;
-      if ((unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W &&
-          c < a.Cin) {
-        const size_t sp = (size_t)z * plane + (size_t)y * a.W + x;
-        v = inb[(size_t)c * vol + sp];
-        if (scb) v *= scb[sp];
-      }
-      in_s[cl * G::P + r] = v;
-    }
-    // ---- stage the weight slice: [KC/2][T][COUT][2] from [Cinp/2][T][Coutp][2] ----
-    {
-      const float* wsrc = a.wpk + ((size_t)(c0 >> 1) * G::T * a.Coutp + co0) * 2;
-      constexpr int ROWQ = G::COUT * 2 / 4;                 // float4 per (cinpair, tap) row
-      constexpr int NQ = (G::KC / 2) * G::T * ROWQ;
-      for (int e = tid; e < NQ; e += 256) {
-        const int row = e / ROWQ, q = e - row * ROWQ;
-        const float4 v = reinterpret_cast<const float4*>(wsrc + (size_t)row * a.Coutp * 2)[q];
-        reinterpret_cast<float4*>(w_s)[e] = v;
-      }
-    }
+    commit();
     __syncthreads();
-    // ---- MFMA stream: one k-step (4 input channels) per tap ----
+    if (c0 + G::KC < a.Cin) fetch(c0 + G::KC);
+    // ---- MFMA stream: one k-step (4 input channels) per tap.  (dz,dy) are real loops so the
+    // scheduler's window -- and with it the number of LDS fragments it keeps in flight in
+    // registers -- stays bounded; dx and the k-steps of a chunk are unrolled inside ----
+#pragma unroll 1
+    for (int dzy = 0; dzy < G::KS * G::KS; ++dzy) {
+      const int dz = dzy / G::KS, dy = dzy - dz * G::KS;
+      const float* arow = in_s + (dz * G::IY + dy) * G::IX;
+      const float* brow = w_s + bbase + dzy * G::KS * G::COUT * 2;
 #pragma unroll
-    for (int dz = 0; dz < G::KS; ++dz)
+      for (int dx = 0; dx < G::KS; ++dx) {
 #pragma unroll
-      for (int dy = 0; dy < G::KS; ++dy)
+        for (int ks = 0; ks < G::KC / 4; ++ks) {
+          float bf[G::NT];
 #pragma unroll
-        for (int dx = 0; dx < G::KS; ++dx) {
-          const int tap = (dz * G::KS + dy) * G::KS + dx;
-          const int toff = (dz * G::IY + dy) * G::IX + dx;
+          for (int n = 0; n < G::NT; ++n) bf[n] = brow[((ks * 2 * G::T + dx) * G::COUT + n * 16) * 2];
 #pragma unroll
-          for (int ks = 0; ks < G::KC / 4; ++ks) {
-            float bf[G::NT];
+          for (int m = 0; m < G::MT; ++m) {
+            const float av = arow[abase[m] + ks * 4 * G::P + dx];
 #pragma unroll
             for (int n = 0; n < G::NT; ++n)
-              bf[n] = w_s[bbase + ((ks * 2 * G::T + tap) * G::COUT + n * 16) * 2];
-#pragma unroll
-            for (int m = 0; m < G::MT; ++m) {
-              const float av = in_s[abase[m] + ks * 4 * G::P + toff];
-#pragma unroll
-              for (int n = 0; n < G::NT; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bf[n], acc[m][n], 0, 0, 0);
-            }
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bf[n], acc[m][n], 0, 0, 0);
           }
         }
+      }
+    }
   }
 
   // ---- epilogue: BN scale/bias, residual, activation, store (lane = 4 x of one channel) ----
@@ -221,7 +255,15 @@ int launch_conv(ConvArgs a, hipStream_t s) {
   a.nco = a.Coutp / G::COUT;
   const long long blocks = (long long)a.B * a.nco * a.ntz * a.nty * a.ntx;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return DV_ERR_SHAPE;
-  hipLaunchKernelGGL(conv3d_mfma_kernel<G>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  // the `volume * noise` prologue is specialised away for the hot Cout=32 layers that never use it
+  constexpr bool kSpecialise = (G::KS == 3 && G::S == 1 && G::NT == 2);
+  if constexpr (kSpecialise) {
+    if (!a.in_scale) {
+      hipLaunchKernelGGL((conv3d_mfma_kernel<G, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+      return dv_launch_status();
+    }
+  }
+  hipLaunchKernelGGL((conv3d_mfma_kernel<G, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);
   return dv_launch_status();
 }
 
@@ -271,22 +313,26 @@ extern "C" int dv_conv3d_f32(const float* in, const float* wpacked, const float*
   a.vec_store = (a.Wo % 4 == 0) && dv_aligned16(out) && (!residual || dv_aligned16(residual));
   a.ntx = a.nty = a.ntz = a.nco = 0;
   hipStream_t s = (hipStream_t)stream;
-  //            KS S NT MTX TH TD KC
+  // One 256-thread block per CU with the whole 512-entry register file per wave (WPS=1): big output
+  // bricks, next chunk prefetched in registers.  KS S NT MTX TH TD KC WPS
   if (k == 3 && stride == 1) {
-    if (a.Coutp == 16) return launch_conv<Geo<3, 1, 1, 2, 4, 4, 8>>(a, s);
+    if (a.Coutp == 16) return launch_conv<Geo<3, 1, 1, 2, 4, 4, 4, 2>>(a, s);
     if (a.Coutp == 32) {
-      if (a.Wo % 48 == 0) return launch_conv<Geo<3, 1, 2, 3, 4, 4, 4>>(a, s);
-      return launch_conv<Geo<3, 1, 2, 2, 4, 4, 8>>(a, s);
+      static const int variant = getenv("DV_CONV_VARIANT") ? atoi(getenv("DV_CONV_VARIANT")) : 0;
+      if (a.Wo % 48 == 0 && variant == 0) return launch_conv<Geo<3, 1, 2, 3, 4, 4, 4, 2>>(a, s);
+      return launch_conv<Geo<3, 1, 2, 2, 4, 4, 4, 2>>(a, s);
     }
-    return launch_conv<Geo<3, 1, 4, 2, 4, 4, 4>>(a, s);
+    static const int v64 = getenv("DV_CONV64_VARIANT") ? atoi(getenv("DV_CONV64_VARIANT")) : 0;
+    if (v64 == 1) return launch_conv<Geo<3, 1, 4, 2, 4, 4, 4, 2>>(a, s);
+    return launch_conv<Geo<3, 1, 4, 2, 4, 2, 4, 2>>(a, s);
   }
   if (k == 3 && stride == 2) {
-    if (a.Coutp == 16) return launch_conv<Geo<3, 2, 1, 2, 4, 2, 4>>(a, s);
-    if (a.Coutp == 32) return launch_conv<Geo<3, 2, 2, 2, 4, 2, 4>>(a, s);
-    return launch_conv<Geo<3, 2, 4, 2, 4, 2, 4>>(a, s);
+    if (a.Coutp == 16) return launch_conv<Geo<3, 2, 1, 2, 4, 2, 4, 2>>(a, s);
+    if (a.Coutp == 32) return launch_conv<Geo<3, 2, 2, 2, 4, 2, 4, 2>>(a, s);
+    return launch_conv<Geo<3, 2, 4, 2, 4, 2, 4, 2>>(a, s);
   }
   // k == 1
-  if (a.Coutp == 16) return launch_conv<Geo<1, 1, 1, 2, 4, 4, 8>>(a, s);
-  if (a.Coutp == 32) return launch_conv<Geo<1, 1, 2, 2, 4, 4, 8>>(a, s);
-  return launch_conv<Geo<1, 1, 4, 2, 4, 4, 8>>(a, s);
+  if (a.Coutp == 16) return launch_conv<Geo<1, 1, 1, 2, 4, 4, 8, 2>>(a, s);
+  if (a.Coutp == 32) return launch_conv<Geo<1, 1, 2, 2, 4, 4, 8, 2>>(a, s);
+  return launch_conv<Geo<1, 1, 4, 2, 4, 4, 8, 2>>(a, s);
 }

@@ -13,6 +13,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
+from .profiling import timed
 
 __all__ = ["build_gwc_volume", "build_concat_volume", "build_concat_attention_volume",
            "disparity_regression", "upsample_softmax_regress", "Conv3dPlan", "Deconv3dPlan",
@@ -47,8 +48,10 @@ def build_gwc_volume(refimg_fea: torch.Tensor, targetimg_fea: torch.Tensor, maxd
     out = torch.empty((b, num_groups, maxdisp, h, w), dtype=torch.float32, device=ref.device)
     lib = _lib.load()
     with torch.cuda.device(ref.device):
-        _lib.check(lib.dv_gwc_volume_f32(ref.data_ptr(), tgt.data_ptr(), out.data_ptr(), b, c, h, w,
-                                         maxdisp, num_groups, _lib.stream_ptr()), "dv_gwc_volume_f32")
+        timed("gwc_volume", 2.0 * out.numel() * (c // num_groups), 4.0 * (2 * ref.numel() + out.numel()),
+              lambda: _lib.check(lib.dv_gwc_volume_f32(ref.data_ptr(), tgt.data_ptr(), out.data_ptr(), b, c, h, w,
+                                                       maxdisp, num_groups, _lib.stream_ptr()),
+                                 "dv_gwc_volume_f32"))
     return out
 
 
@@ -83,9 +86,10 @@ def build_concat_attention_volume(refimg_fea: torch.Tensor, targetimg_fea: torch
     out = torch.empty((b, 2 * c, maxdisp, h, w), dtype=torch.float32, device=ref.device)
     lib = _lib.load()
     with torch.cuda.device(ref.device):
-        _lib.check(lib.dv_concat_attn_volume_f32(ref.data_ptr(), tgt.data_ptr(), att.data_ptr(),
-                                                 out.data_ptr(), b, c, h, w, maxdisp, _lib.stream_ptr()),
-                   "dv_concat_attn_volume_f32")
+        timed("concat_attn_volume", 2.0 * out.numel(), 4.0 * (2 * ref.numel() + att.numel() + out.numel()),
+              lambda: _lib.check(lib.dv_concat_attn_volume_f32(ref.data_ptr(), tgt.data_ptr(), att.data_ptr(),
+                                                               out.data_ptr(), b, c, h, w, maxdisp,
+                                                               _lib.stream_ptr()), "dv_concat_attn_volume_f32"))
     return out
 
 
@@ -121,10 +125,11 @@ def upsample_softmax_regress(cost: torch.Tensor, want_uncertainty: bool = True,
     unc = torch.empty_like(disp) if want_uncertainty else None
     lib = _lib.load()
     with torch.cuda.device(cost.device):
-        _lib.check(lib.dv_upsample_softmax_regress_f32(cost.data_ptr(), disp.data_ptr(), _lib.ptr(unc),
-                                                       b, d, h, w, int(bool(align_corners)),
-                                                       _lib.stream_ptr()),
-                   "dv_upsample_softmax_regress_f32")
+        timed("upsample_softmax_regress", 0.0, 4.0 * (cost.numel() + 2 * disp.numel()),
+              lambda: _lib.check(lib.dv_upsample_softmax_regress_f32(cost.data_ptr(), disp.data_ptr(),
+                                                                     _lib.ptr(unc), b, d, h, w,
+                                                                     int(bool(align_corners)), _lib.stream_ptr()),
+                                 "dv_upsample_softmax_regress_f32"))
     return disp, unc
 
 
@@ -176,10 +181,15 @@ class Conv3dPlan:
                 raise RuntimeError("residual shape mismatch")
         lib = _lib.load()
         with torch.cuda.device(x.device):
-            _lib.check(lib.dv_conv3d_f32(x.data_ptr(), self.wpacked.data_ptr(), _lib.ptr(self.scale),
-                                         _lib.ptr(self.shift), _lib.ptr(in_scale), _lib.ptr(residual),
-                                         out.data_ptr(), b, cin, d, h, w, self.cout, self.k,
-                                         self.stride, self.act, _lib.stream_ptr()), "dv_conv3d_f32")
+            nb = 4.0 * (x.numel() + out.numel() + (0 if in_scale is None else in_scale.numel())
+                        + (0 if residual is None else residual.numel()))
+            timed(f"conv3d_k{self.k}s{self.stride}_co{self.cout}",
+                  2.0 * out.numel() * cin * self.k ** 3, nb,
+                  lambda: _lib.check(lib.dv_conv3d_f32(x.data_ptr(), self.wpacked.data_ptr(), _lib.ptr(self.scale),
+                                                       _lib.ptr(self.shift), _lib.ptr(in_scale),
+                                                       _lib.ptr(residual), out.data_ptr(), b, cin, d, h, w,
+                                                       self.cout, self.k, self.stride, self.act,
+                                                       _lib.stream_ptr()), "dv_conv3d_f32"))
         return out
 
 
@@ -215,10 +225,13 @@ class Deconv3dPlan:
                 raise RuntimeError("residual shape mismatch")
         lib = _lib.load()
         with torch.cuda.device(x.device):
-            _lib.check(lib.dv_deconv3d_k3s2_f32(x.data_ptr(), self.wpacked.data_ptr(), _lib.ptr(self.scale),
-                                                _lib.ptr(self.shift), _lib.ptr(residual), out.data_ptr(),
-                                                b, cin, d, h, w, self.cout, self.act, _lib.stream_ptr()),
-                       "dv_deconv3d_k3s2_f32")
+            nb = 4.0 * (x.numel() + out.numel() * (1 if residual is None else 2))
+            timed("deconv3d_k3s2", 2.0 * x.numel() * self.cout * 27, nb,
+                  lambda: _lib.check(lib.dv_deconv3d_k3s2_f32(x.data_ptr(), self.wpacked.data_ptr(),
+                                                              _lib.ptr(self.scale), _lib.ptr(self.shift),
+                                                              _lib.ptr(residual), out.data_ptr(), b, cin, d, h, w,
+                                                              self.cout, self.act, _lib.stream_ptr()),
+                                     "dv_deconv3d_k3s2_f32"))
         return out
 
 
@@ -248,8 +261,10 @@ def window_attention(x: torch.Tensor, qkv_w: torch.Tensor, qkv_b: torch.Tensor, 
     out = torch.empty_like(x)
     lib = _lib.load()
     with torch.cuda.device(x.device):
-        _lib.check(lib.dv_window_attn3d_f32(x.data_ptr(), qkv_w.data_ptr(), qkv_b.data_ptr(),
-                                            proj_w.data_ptr(), proj_b.data_ptr(), out.data_ptr(),
-                                            b, c, d, h, w, heads, _lib.stream_ptr()),
-                   "dv_window_attn3d_f32")
+        ntok = float(b * d * h * w)
+        timed("window_attn3d", ntok * (2.0 * c * 3 * c + 2.0 * c * c + 4.0 * 64 * c), 8.0 * x.numel(),
+              lambda: _lib.check(lib.dv_window_attn3d_f32(x.data_ptr(), qkv_w.data_ptr(), qkv_b.data_ptr(),
+                                                          proj_w.data_ptr(), proj_b.data_ptr(), out.data_ptr(),
+                                                          b, c, d, h, w, heads, _lib.stream_ptr()),
+                                 "dv_window_attn3d_f32"))
     return out

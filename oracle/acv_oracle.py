@@ -204,7 +204,7 @@ def encode_two_hot(disp_q: Tensor, nbins: int = 48) -> Tensor:
     [B,1,h,w] (or [B,1,1,h,w]) -> two-hot distribution over ``nbins`` (values in
     [0,1], before the *2-1 rescale).  Bin floor(d) gets 1-frac, the next bin
     (clamped) gets frac; floor(d)==nbins-1 is forced to a pure last-bin one-hot."""
-    dq = disp_q.reshape(disp_q.shape[0], 1, disp_q.shape[-2], disp_q.shape[-1])
+    dq = disp_q.reshape(disp_q.shape[0], 1, disp_q.shape[-2], disp_q.shape[-1]).float()
     b, _, h, w = dq.shape
     real = torch.floor(dq).long()
     coff = real - dq + 1

@@ -64,9 +64,9 @@ def test_encoder_and_schedule():
     assert th[3, 1] == 0.75 and th[4, 1] == 0.25
     np.testing.assert_allclose(th[46:, 2].numpy(), [0.1, 0.9], atol=1e-5)
     assert th[47, 3] == 1 and th[47, 4] == 1 and th[:47, 4].sum() == 0
-    close(orc.alphas_cumprod, g["alphas_cumprod"])
-    close(orc.sqrt_recip_alphas_cumprod, g["sqrt_recip"])
-    close(orc.sqrt_recipm1_alphas_cumprod, g["sqrt_recipm1"])
+    close(orc.alphas_cumprod, g["alphas_cumprod"], rtol=1e-13)        # libm cos() may differ by an ulp across CPUs
+    close(orc.sqrt_recip_alphas_cumprod, g["sqrt_recip"], rtol=1e-13)
+    close(orc.sqrt_recipm1_alphas_cumprod, g["sqrt_recipm1"], rtol=1e-13)
     assert abs(float(orc.sqrt_recip_alphas_cumprod[999]) - 20291.17) < 0.01
     for s in (2, 3, 5, 20):
         pairs = O.ddim_time_pairs(1000, s)

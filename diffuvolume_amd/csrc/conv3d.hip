@@ -229,6 +229,145 @@ __global__ __launch_bounds__(256, G::WPS) void conv3d_mfma_kernel(ConvArgs a) {
   }
 }
 
+// ---- Cout == 1 (the classifier head, acv_ddim.py:214/:222): a single output channel would waste
+// 15/16 of every MFMA tile, so this layer runs on the vector ALU.  A block owns a 4 x 8 x 64 output
+// brick; each thread 8 consecutive x of one (z,y) row, i.e. 8 accumulators fed by 9 LDS rows of 10
+// floats per input channel (two ds_read_b128 + one ds_read_b64 per row, conflict-free), with the 27
+// weights of the channel in scalar registers.  Reads the input once: HBM-bound in the limit.
+namespace c1 {
+constexpr int TZ = 4, TY = 8, TX = 64, XT = 8, KCV = 2;
+constexpr int IZ = TZ + 2, IY = TY + 2, IX = TX + 2, RW = 68;   // RW/4 odd: rows alternate 16-B slot parity
+constexpr int PLANE = IZ * IY * RW;
+}  // namespace c1
+
+template <bool HAS_SCALE>
+__global__ __launch_bounds__(256, 2) void conv3d_c1_kernel(ConvArgs a) {
+  using namespace c1;
+  __shared__ __attribute__((aligned(16))) float in_s[KCV * PLANE];
+  const int tid = threadIdx.x;
+  unsigned t = dv_xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = t % a.ntx; t /= a.ntx;
+  const int ty = t % a.nty; t /= a.nty;
+  const int tz = t % a.ntz;
+  const int b = t / a.ntz;
+  const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
+  const int row = tid >> 3, xs = (tid & 7) * XT;
+  const int zl = row / TY, yl = row % TY;
+  const size_t plane = (size_t)a.H * a.W, vol = (size_t)a.D * plane;
+  const float* inb = a.in + (size_t)b * a.Cin * vol;
+  const float* scb = (HAS_SCALE && a.in_scale) ? a.in_scale + (size_t)b * vol : nullptr;
+  const float* w = a.wpk;  // raw [1][Cin][27] weights for this path
+
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  float acc[XT];
+#pragma unroll
+  for (int i = 0; i < XT; ++i) acc[i] = 0.f;
+
+  // Staging: one wave per brick row, lanes on the 64 interior x (aligned 256-byte segments); the two
+  // halo columns of all rows are one extra element per thread.  Row coordinates are wave-uniform.
+  // The next chunk is fetched into registers before the current one is consumed.
+  constexpr int NR = KCV * IZ * IY / 4;        // rows per wave and chunk
+  static_assert(KCV * IZ * IY % 4 == 0 && KCV * IZ * IY * 2 <= 256, "staging plan");
+  float vmain[NR], vhalo = 0.f;
+  const int he = tid;                            // halo element: (cl, zz, yy, side)
+  const int hcl = he / (IZ * IY * 2), hr = he % (IZ * IY * 2);
+  const int hzz = (hr >> 1) / IY, hyy = (hr >> 1) % IY, hxx = (hr & 1) ? IX - 1 : 0;
+  const bool hlive = he < KCV * IZ * IY * 2;
+  // (c,z,y) are wave-uniform for the row loads: the row pointer lives in scalar registers and the
+  // lane only contributes a 32-bit offset
+  auto ldrow = [&](int c, int z, int y, int xoff) -> float {
+    const bool rok = c < a.Cin && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H;
+    const int x = x0 + xoff;
+    if (!rok || (unsigned)x >= (unsigned)a.W) return 0.f;
+    const size_t rowo = (size_t)z * plane + (size_t)y * a.W + x0;
+    float v = (inb + (size_t)c * vol + rowo)[xoff];
+    if (HAS_SCALE && scb) v *= (scb + rowo)[xoff];
+    return v;
+  };
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int it = 0; it < NR; ++it) {
+      const int rr = wave + 4 * it;
+      const int cl = rr / (IZ * IY), r2 = rr - cl * (IZ * IY);
+      const int zz = r2 / IY, yy = r2 - zz * IY;
+      vmain[it] = ldrow(c0 + cl, z0 - 1 + zz, y0 - 1 + yy, lane);
+    }
+    if (hlive) vhalo = ldrow(c0 + hcl, z0 - 1 + hzz, y0 - 1 + hyy, hxx - 1);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < NR; ++it) {
+      const int rr = wave + 4 * it;
+      const int cl = rr / (IZ * IY), r2 = rr - cl * (IZ * IY);
+      in_s[cl * PLANE + r2 * RW + 1 + lane] = vmain[it];
+    }
+    if (hlive) in_s[hcl * PLANE + (hzz * IY + hyy) * RW + hxx] = vhalo;
+  };
+
+  fetch(0);
+  for (int c0 = 0; c0 < a.Cin; c0 += KCV) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (c0 + KCV < a.Cin) fetch(c0 + KCV);
+#pragma unroll 1
+    for (int cl = 0; cl < KCV; ++cl) {
+      if (c0 + cl >= a.Cin) break;
+      const float* wc = w + (size_t)(c0 + cl) * 27;          // wave-uniform -> scalar loads
+#pragma unroll 1
+      for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const float* rp = in_s + cl * PLANE + ((zl + dz) * IY + (yl + dy)) * RW + xs;
+          const float4 q0 = *reinterpret_cast<const float4*>(rp);
+          const float4 q1 = *reinterpret_cast<const float4*>(rp + 4);
+          const float2 q2 = *reinterpret_cast<const float2*>(rp + 8);
+          const float v[10] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y};
+          const float w0 = wc[(dz * 3 + dy) * 3], w1 = wc[(dz * 3 + dy) * 3 + 1], w2 = wc[(dz * 3 + dy) * 3 + 2];
+#pragma unroll
+          for (int i = 0; i < XT; ++i) {
+            acc[i] = fmaf(v[i], w0, acc[i]);
+            acc[i] = fmaf(v[i + 1], w1, acc[i]);
+            acc[i] = fmaf(v[i + 2], w2, acc[i]);
+          }
+        }
+    }
+  }
+  const int zo = z0 + zl, yo = y0 + yl, xo = x0 + xs;
+  if (zo >= a.Do || yo >= a.Ho || xo >= a.Wo) return;
+  const float sc = a.ch_scale ? a.ch_scale[0] : 1.f, bi = a.ch_bias ? a.ch_bias[0] : 0.f;
+  const size_t o = (size_t)b * a.Do * a.Ho * a.Wo + ((size_t)zo * a.Ho + yo) * a.Wo + xo;
+#pragma unroll
+  for (int i = 0; i < XT; ++i) {
+    float u = fmaf(acc[i], sc, bi);
+    if (xo + i < a.Wo) {
+      if (a.residual) u += a.residual[o + i];
+      acc[i] = dv_act(u, a.act);
+    }
+  }
+  if (a.vec_store && xo + XT <= a.Wo) {
+    *reinterpret_cast<float4*>(a.out + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4*>(a.out + o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < XT; ++i)
+      if (xo + i < a.Wo) a.out[o + i] = acc[i];
+  }
+}
+
+int launch_c1(ConvArgs a, hipStream_t s) {
+  a.ntx = (a.Wo + c1::TX - 1) / c1::TX;
+  a.nty = (a.Ho + c1::TY - 1) / c1::TY;
+  a.ntz = (a.Do + c1::TZ - 1) / c1::TZ;
+  const long long blocks = (long long)a.B * a.ntz * a.nty * a.ntx;
+  if (blocks <= 0 || blocks > 0x7fffffffLL) return DV_ERR_SHAPE;
+  if (a.in_scale)
+    hipLaunchKernelGGL(conv3d_c1_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(conv3d_c1_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  return dv_launch_status();
+}
+
 __global__ void pack_conv_weights_kernel(const float* __restrict__ w, float* __restrict__ wpk, int Cin,
                                          int Cout, int T, int Cinp, int Coutp) {
   const size_t total = (size_t)Cinp * T * Coutp;
@@ -271,6 +410,7 @@ int launch_conv(ConvArgs a, hipStream_t s) {
 
 extern "C" size_t dv_conv3d_packed_floats(int Cin, int Cout, int k) {
   if (Cin <= 0 || Cout <= 0 || (k != 1 && k != 3)) return 0;
+  if (Cout == 1 && k == 3) return (size_t)pad_to(Cin * 27, 4);      // vector-ALU path: raw [Cin][27]
   return (size_t)pad_to(Cin, 8) * (k * k * k) * coutp_of(Cout);
 }
 
@@ -280,6 +420,11 @@ extern "C" int dv_conv3d_pack_weights_f32(const float* w, float* wpacked, int Ci
   DV_REQUIRE_PTR(wpacked);
   DV_REQUIRE(Cin > 0 && Cout > 0, DV_ERR_SHAPE);
   DV_REQUIRE(k == 1 || k == 3, DV_ERR_UNSUPPORTED);
+  if (Cout == 1 && k == 3) {
+    hipError_t e = hipMemcpyAsync(wpacked, w, (size_t)Cin * 27 * sizeof(float), hipMemcpyDeviceToDevice,
+                                  (hipStream_t)stream);
+    return e == hipSuccess ? DV_OK : (int)e;
+  }
   const int T = k * k * k, Cinp = pad_to(Cin, 8), Coutp = coutp_of(Cout);
   const size_t total = (size_t)Cinp * T * Coutp;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
@@ -316,6 +461,7 @@ extern "C" int dv_conv3d_f32(const float* in, const float* wpacked, const float*
   // One 256-thread block per CU with the whole 512-entry register file per wave (WPS=1): big output
   // bricks, next chunk prefetched in registers.  KS S NT MTX TH TD KC WPS
   if (k == 3 && stride == 1) {
+    if (Cout == 1) return launch_c1(a, s);
     if (a.Coutp == 16) return launch_conv<Geo<3, 1, 1, 2, 4, 4, 4, 2>>(a, s);
     if (a.Coutp == 32) {
       static const int variant = getenv("DV_CONV_VARIANT") ? atoi(getenv("DV_CONV_VARIANT")) : 0;

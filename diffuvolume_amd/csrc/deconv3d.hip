@@ -69,52 +69,83 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
   const size_t plane = (size_t)a.H * a.W, vol = (size_t)a.D * plane;
   const float* inb = a.in + (size_t)b * a.Cin * vol;
 
+  // staging plan (same scheme as conv3d.hip): each thread owns NS positions of the haloed input
+  // brick; the next chunk's global loads are issued before the current chunk's MFMA stream
+  constexpr int NS = (kPRAW + 255) / 256;
+  constexpr int ROWQ = kCOUT * 2 / 4;
+  constexpr int NQ = (kKC / 2) * kT * ROWQ;
+  constexpr int NWQ = (NQ + 255) / 256;
+  int sp[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int r = tid + 256 * i;
+    const int zz = r / (kIY * kIX), r2 = r - zz * (kIY * kIX);
+    const int yy = r2 / kIX, xx = r2 - yy * kIX;
+    const int z = z0 + zz, y = y0 + yy, x = x0 + xx;
+    sp[i] = (r < kPRAW && z < a.D && y < a.H && x < a.W) ? (z * a.H + y) * a.W + x : -1;
+  }
+  float vin[kKC][NS];
+  f32x4 vw[NWQ];
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int cl = 0; cl < kKC; ++cl) {
+      const float* src = inb + (size_t)(c0 + cl) * vol;
+      const bool cok = (c0 + cl) < a.Cin;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) vin[cl][i] = (cok && sp[i] >= 0) ? src[sp[i]] : 0.f;
+    }
+    const float* wsrc = a.wpk + ((size_t)(c0 >> 1) * kT * a.Coutp + co0) * 2;
+#pragma unroll
+    for (int q = 0; q < NWQ; ++q) {
+      const int e = tid + 256 * q;
+      const int row = e / ROWQ, qq = e - row * ROWQ;
+      if (e < NQ) vw[q] = reinterpret_cast<const f32x4*>(wsrc + (size_t)row * a.Coutp * 2)[qq];
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int cl = 0; cl < kKC; ++cl)
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const int r = tid + 256 * i;
+        if (r < kPRAW) in_s[cl * kP + r] = vin[cl][i];
+      }
+#pragma unroll
+    for (int q = 0; q < NWQ; ++q) {
+      const int e = tid + 256 * q;
+      if (e < NQ) reinterpret_cast<f32x4*>(w_s)[e] = vw[q];
+    }
+  };
+
+  fetch(0);
   for (int c0 = 0; c0 < a.Cin; c0 += kKC) {
     __syncthreads();
-#pragma unroll 2
-    for (int e = tid; e < kKC * kPRAW; e += 256) {
-      const int cl = e / kPRAW, r = e - cl * kPRAW;
-      const int zz = r / (kIY * kIX), r2 = r - zz * (kIY * kIX);
-      const int yy = r2 / kIX, xx = r2 - yy * kIX;
-      const int z = z0 + zz, y = y0 + yy, x = x0 + xx, c = c0 + cl;
-      float v = 0.f;
-      if (z < a.D && y < a.H && x < a.W && c < a.Cin) v = inb[(size_t)c * vol + (size_t)z * plane + (size_t)y * a.W + x];
-      in_s[cl * kP + r] = v;
-    }
-    {
-      const float* wsrc = a.wpk + ((size_t)(c0 >> 1) * kT * a.Coutp + co0) * 2;
-      constexpr int ROWQ = kCOUT * 2 / 4;
-      constexpr int NQ = (kKC / 2) * kT * ROWQ;
-      for (int e = tid; e < NQ; e += 256) {
-        const int row = e / ROWQ, q = e - row * ROWQ;
-        reinterpret_cast<float4*>(w_s)[e] =
-            reinterpret_cast<const float4*>(wsrc + (size_t)row * a.Coutp * 2)[q];
-      }
-    }
+    commit();
     __syncthreads();
+    if (c0 + kKC < a.Cin) fetch(c0 + kKC);
 #pragma unroll
-    for (int kz = 0; kz < 3; ++kz)
+    for (int kzy = 0; kzy < 9; ++kzy) {
+      const int kz = kzy / 3, ky = kzy - kz * 3;
+      const float* arow = in_s + abase + ((kz == 0) * kIY + (ky == 0)) * kIX;
+      const float* brow = w_s + bbase + kzy * 3 * kCOUT * 2;
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
+      for (int kx = 0; kx < 3; ++kx) {
+        const int cls = ((kz != 1) << 2) | ((ky != 1) << 1) | (kx != 1);
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int tap = (kz * 3 + ky) * 3 + kx;
-          const int cls = ((kz != 1) << 2) | ((ky != 1) << 1) | (kx != 1);
-          const int toff = ((kz == 0) * kIY + (ky == 0)) * kIX + (kx == 0);
+        for (int ks = 0; ks < kKC / 4; ++ks) {
+          float bf[kNT];
 #pragma unroll
-          for (int ks = 0; ks < kKC / 4; ++ks) {
-            float bf[kNT];
+          for (int n = 0; n < kNT; ++n) bf[n] = brow[((ks * 2 * kT + kx) * kCOUT + n * 16) * 2];
 #pragma unroll
-            for (int n = 0; n < kNT; ++n) bf[n] = w_s[bbase + ((ks * 2 * kT + tap) * kCOUT + n * 16) * 2];
+          for (int m = 0; m < kMTX; ++m) {
+            const float av = arow[m * 16 + ks * 4 * kP + (kx == 0)];
 #pragma unroll
-            for (int m = 0; m < kMTX; ++m) {
-              const float av = in_s[abase + m * 16 + ks * 4 * kP + toff];
-#pragma unroll
-              for (int n = 0; n < kNT; ++n)
-                acc[m][cls][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bf[n], acc[m][cls][n], 0, 0, 0);
-            }
+            for (int n = 0; n < kNT; ++n)
+              acc[m][cls][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bf[n], acc[m][cls][n], 0, 0, 0);
           }
         }
+      }
+    }
   }
 
   // epilogue: px=0 / px=1 classes interleave along x -> 8 consecutive outputs per lane

@@ -44,7 +44,7 @@ def test_argument_validation_without_gpu(built):
     lib = _lib.load()
     assert lib.dv_gwc_volume_f32(None, None, None, 1, 8, 2, 4, 2, 4, None) == -1
     assert lib.dv_conv3d_packed_floats(32, 32, 3) == 32 * 27 * 32
-    assert lib.dv_conv3d_packed_floats(40, 1, 3) == 40 * 27 * 16
+    assert lib.dv_conv3d_packed_floats(40, 1, 3) == 40 * 27          # single-channel head: raw weights
     assert lib.dv_conv3d_packed_floats(32, 32, 5) == 0
     assert lib.dv_deconv3d_packed_floats(128, 64) == 128 * 27 * 64
 

@@ -37,6 +37,24 @@ ALGO_BYTES_PER_PAIR = 23.2e9      # ideal-fusion fp32 HBM bytes of 
 ALGO_FLOP_PER_PAIR = 3.76e12
 
 
+DOMINANT_KERNEL = "conv3d_mfma_kernel<Geo<3, 1, 2, 3, 4, 4, 4, 2>, false>"
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+    this same command (profiles/*_pmc_traffic.json, gfx950 x2 read correction applied); None if absent."""
+    files = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))
+    if not files:
+        return None
+    try:
+        for k in json.loads(files[-1].read_text())["kernels"]:
+            if k["kernel"] == kernel:
+                return k["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,8 +197,8 @@ def main():
         if dom:
             ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": None,
-                               "kernel": "conv3d_mfma_kernel (k3 s1 Cout=32: dres0/dres1/classif2 convs)",
+                               "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": pmc_traffic(DOMINANT_KERNEL),
+                               "kernel": DOMINANT_KERNEL + " (the 32->32 k3 convs of dres0/dres1/classif2)",
                                "launches": dom["launches"], "avg_ms": dom["avg_ms"],
                                "algorithmic_gflop_per_launch": dom["flops"] / dom["launches"] / 1e9}
         out["kernels_ms_per_step"] = {k: round(v["total_ms"] / a.steps, 3) for k, v in sorted(ks.items())}

@@ -183,7 +183,7 @@ class Conv3dPlan:
         with torch.cuda.device(x.device):
             nb = 4.0 * (x.numel() + out.numel() + (0 if in_scale is None else in_scale.numel())
                         + (0 if residual is None else residual.numel()))
-            timed(f"conv3d_k{self.k}s{self.stride}_co{self.cout}",
+            timed(f"conv3d_k{self.k}s{self.stride}_co{self.cout}" + ("" if in_scale is None else "_filter"),
                   2.0 * out.numel() * cin * self.k ** 3, nb,
                   lambda: _lib.check(lib.dv_conv3d_f32(x.data_ptr(), self.wpacked.data_ptr(), _lib.ptr(self.scale),
                                                        _lib.ptr(self.shift), _lib.ptr(in_scale),

@@ -150,6 +150,17 @@ int dv_ddim_step(const float* disp, const float* unc, const float* used,
                  float* mask, float* x_start, double* pred_eps, double* x_next, float* ens,
                  int B, int nbins, int h, int w, const dv_ddim_coef* coef, dv_stream_t stream);
 
+/* ---- IGEV: geometry-encoding-volume lookup with the noise filter -----------------------
+ * Combined_Geo_Encoding_Volume.__call__ (KITTI15/core/geometry_ddim.py:33-69), 2 pyramid levels,
+ * radius 4: per pixel, (geo[c,:] * noise[:]) linearly sampled at disp/2^i + {-4..4} plus the all-pairs
+ * correlation row sampled at coords/2^i - disp/2^i + {-4..4}.
+ * geo [B,C,D,h,w]; corr0 [B,h,w,W2] (= corr() :72-80), corr1 [B,h,w,W2/2] (its avg_pool, :28-30);
+ * disp, coords [B,h,w]; noisy: the [B,D,h,w] filter tensor, read as B*h*w rows of D floats (the
+ * reference's raw reshape, :37); out [B, 2*(9C+9), h, w], channel order (geo0, corr0, geo1, corr1). */
+int dv_geo_filter_lookup_f32(const float* geo, const float* corr0, const float* corr1,
+                             const float* disp, const float* coords, const float* noisy, float* out,
+                             int B, int C, int D, int h, int w, int W2, int radius, dv_stream_t stream);
+
 /* ---- metrics (SceneFlow/utils/metrics.py:22-65) -------------------------------
  * Per-image sums over pixels with mask!=0: sums[b] = { n_mask, n_gt_pos, sum|gt-est|,
  * n_D1 (err>3 & err/|gt|>0.05), n_err>1, n_err>2, n_err>3, 0 } as fp64 [B,8].

@@ -365,3 +365,28 @@ def test_metrics_golden():
     assert abs(float(M.EPE_metric(dev(g["est"]), dev(g["gt"]), dev(g["mask"]))) - g["EPE"]) < 1e-6
     g = load_golden("metrics_all_skipped")
     assert float(M.batch_metrics(dev(g["est"]), dev(g["gt"]), dev(g["mask"]))["EPE"]) == 0.0
+
+
+# ---------------------------------------------------------------- IGEV geometry lookup
+def test_igev_geo_filter_lookup_golden():
+    from diffuvolume_amd.geometry_ddim import Combined_Geo_Encoding_Volume
+    g = load_golden("igev_geo_lookup")
+    fn = Combined_Geo_Encoding_Volume(dev(g["f1"]), dev(g["f2"]), dev(g["geo"]), num_levels=2, radius=4)
+    out = fn(dev(g["disp"]), dev(g["coords"]), dev(g["noisy"]))
+    assert out.shape == g["out"].shape
+    torch.testing.assert_close(out.cpu(), g["out"], atol=2e-5, rtol=1e-5)   # corr GEMM order differs (rocBLAS)
+
+
+def test_igev_geo_filter_lookup_oracle_kitti_size():
+    from diffuvolume_amd.geometry_ddim import Combined_Geo_Encoding_Volume
+    from oracle import igev_oracle as IO
+    b, c, d, h, w = 1, 8, 48, 12, 78                      # 1/4 of a KITTI row band; W odd/4
+    gen = _gen(62, "igev")
+    geo = torch.randn(b, c, d, h, w, generator=gen)
+    f1, f2 = torch.randn(b, 24, h, w, generator=gen), torch.randn(b, 24, h, w, generator=gen)
+    disp = torch.rand(b, 1, h, w, generator=gen) * 47
+    coords = torch.arange(w, dtype=torch.float32).view(1, 1, 1, w).expand(b, 1, h, w).contiguous()
+    noisy = torch.rand(b, d, h, w, generator=gen)
+    ref = IO.geo_filter_lookup(geo, f1, f2, disp, coords, noisy)
+    out = Combined_Geo_Encoding_Volume(dev(f1), dev(f2), dev(geo))(dev(disp), dev(coords), dev(noisy))
+    torch.testing.assert_close(out.cpu(), ref, atol=3e-5, rtol=1e-5)

@@ -161,3 +161,12 @@ def test_metrics():
         assert abs(float(m[k]) - g[k]) < 1e-6, k
     g = load_golden("metrics_all_skipped")
     assert float(O.image_metrics(g["est"], g["gt"], g["mask"].bool())["EPE"]) == 0.0 == g["EPE"]
+
+
+def test_igev_geo_filter_lookup():
+    """KITTI15/core/geometry_ddim.py:33-69 (noise-filtered geometry lookup, 2 levels, radius 4)."""
+    from oracle import igev_oracle as IO
+    g = load_golden("igev_geo_lookup")
+    out = IO.geo_filter_lookup(g["geo"], g["f1"], g["f2"], g["disp"], g["coords"], g["noisy"])
+    assert out.shape == g["out"].shape == (2, 162, 5, 24)
+    torch.testing.assert_close(out, g["out"], atol=2e-6, rtol=1e-6)

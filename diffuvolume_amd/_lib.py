@@ -44,6 +44,7 @@ SIGNATURES = {
     "dv_deconv3d_k3s2_f32": (c_int, [P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "dv_window_attn3d_f32": (c_int, [P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "dv_upsample_softmax_regress_f32": (c_int, [P, P, P, I, I, I, I, I, P]),
+    "dv_upsample_softmax_uncertainty_f32": (c_int, [P, P, P, I, I, I, I, I, P]),
     "dv_disparity_regression_f32": (c_int, [P, P, I, I, I, I, P]),
     "dv_encode_two_hot_f32": (c_int, [P, P, I, I, I, P]),
     "dv_ddim_step": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, POINTER(DvDdimCoef), P]),

@@ -193,12 +193,13 @@ class ProbVolumeHandle:
     quarter-resolution cost and the fused uncertainty; ``dense()`` materialises the softmax
     volume with PyTorch ops for callers that really want it."""
 
-    def __init__(self, cost: torch.Tensor, uncertainty: torch.Tensor, maxdisp: int):
-        self.cost, self.uncertainty, self.maxdisp = cost, uncertainty, maxdisp
+    def __init__(self, cost: torch.Tensor, uncertainty: torch.Tensor, maxdisp: int, align_corners: bool = False):
+        self.cost, self.uncertainty, self.maxdisp, self.align_corners = cost, uncertainty, maxdisp, align_corners
 
     def dense(self) -> torch.Tensor:
         b, _, d, h, w = self.cost.shape
-        up = F.interpolate(self.cost, [self.maxdisp, h * 4, w * 4], mode="trilinear")
+        up = F.interpolate(self.cost, [self.maxdisp, h * 4, w * 4], mode="trilinear",
+                           align_corners=True if self.align_corners else None)
         return F.softmax(up.squeeze(1), dim=1)
 
 

@@ -30,6 +30,7 @@ __device__ __forceinline__ void lin_src(int dst, int in_size, int out_size, int&
 
 template <int D, bool ALIGN>
 __global__ __launch_bounds__(256) void upsample_softmax_regress_kernel(const float* __restrict__ cost,
+                                                                       const float* __restrict__ disp_in,
                                                                        float* __restrict__ disp,
                                                                        float* __restrict__ unc, int h,
                                                                        int w, size_t total) {
@@ -78,13 +79,17 @@ __global__ __launch_bounds__(256) void upsample_softmax_regress_kernel(const flo
     s += expf(v - m);
   }
   float dsp = 0.f;
+  if (disp_in) {           // uncertainty about an externally refined disparity (pwcnet_ddim.py:548-552)
+    dsp = disp_in[i];
+  } else {
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    float v;
-    DV_VK(k, v);
-    dsp += (expf(v - m) / s) * (float)k;
+    for (int k = 0; k < K; ++k) {
+      float v;
+      DV_VK(k, v);
+      dsp += (expf(v - m) / s) * (float)k;
+    }
+    disp[i] = dsp;
   }
-  disp[i] = dsp;
   if (unc) {
     float u = 0.f;
 #pragma unroll
@@ -100,7 +105,8 @@ __global__ __launch_bounds__(256) void upsample_softmax_regress_kernel(const flo
 
 // Any D: the D in-plane costs of a pixel live in LDS (one column per thread).
 template <bool ALIGN>
-__global__ void upsample_softmax_regress_generic(const float* __restrict__ cost, float* __restrict__ disp,
+__global__ void upsample_softmax_regress_generic(const float* __restrict__ cost,
+                                                 const float* __restrict__ disp_in, float* __restrict__ disp,
                                                  float* __restrict__ unc, int D, int h, int w,
                                                  size_t total) {
   extern __shared__ float cs[];  // [D][blockDim.x]
@@ -135,9 +141,11 @@ __global__ void upsample_softmax_regress_generic(const float* __restrict__ cost,
   float s = 0.f;
   for (int k = 0; k < K; ++k) s += expf(vk(k) - m);
   float dsp = 0.f;
-  for (int k = 0; k < K; ++k) dsp += (expf(vk(k) - m) / s) * (float)k;
+  if (!disp_in)
+    for (int k = 0; k < K; ++k) dsp += (expf(vk(k) - m) / s) * (float)k;
   if (!live) return;
-  disp[i] = dsp;
+  if (disp_in) dsp = disp_in[i];
+  else disp[i] = dsp;
   if (unc) {
     float u = 0.f;
     for (int k = 0; k < K; ++k) u += fabsf(dsp - (float)k) * (expf(vk(k) - m) / s);
@@ -158,21 +166,17 @@ __global__ void disparity_regression_kernel(const float* __restrict__ prob, floa
 
 }  // namespace
 
-extern "C" int dv_upsample_softmax_regress_f32(const float* cost, float* disp, float* unc, int B, int D,
-                                               int h, int w, int align_corners, dv_stream_t stream) {
-  DV_REQUIRE_PTR(cost);
-  DV_REQUIRE_PTR(disp);
-  DV_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, DV_ERR_SHAPE);
-  hipStream_t s = (hipStream_t)stream;
+static int launch_tail(const float* cost, const float* disp_in, float* disp, float* unc, int B, int D, int h,
+                       int w, int align_corners, hipStream_t s) {
   const size_t total = (size_t)B * 16 * h * w;
   const unsigned blocks = (unsigned)((total + 255) / 256);
   if (D == 48) {
     if (align_corners)
       hipLaunchKernelGGL((upsample_softmax_regress_kernel<48, true>), dim3(blocks), dim3(256), 0, s, cost,
-                         disp, unc, h, w, total);
+                         disp_in, disp, unc, h, w, total);
     else
       hipLaunchKernelGGL((upsample_softmax_regress_kernel<48, false>), dim3(blocks), dim3(256), 0, s, cost,
-                         disp, unc, h, w, total);
+                         disp_in, disp, unc, h, w, total);
     return dv_launch_status();
   }
   const int threads = 64;
@@ -181,11 +185,29 @@ extern "C" int dv_upsample_softmax_regress_f32(const float* cost, float* disp, f
   const unsigned gblocks = (unsigned)((total + threads - 1) / threads);
   if (align_corners)
     hipLaunchKernelGGL((upsample_softmax_regress_generic<true>), dim3(gblocks), dim3(threads), lds, s, cost,
-                       disp, unc, D, h, w, total);
+                       disp_in, disp, unc, D, h, w, total);
   else
     hipLaunchKernelGGL((upsample_softmax_regress_generic<false>), dim3(gblocks), dim3(threads), lds, s, cost,
-                       disp, unc, D, h, w, total);
+                       disp_in, disp, unc, D, h, w, total);
   return dv_launch_status();
+}
+
+extern "C" int dv_upsample_softmax_regress_f32(const float* cost, float* disp, float* unc, int B, int D,
+                                               int h, int w, int align_corners, dv_stream_t stream) {
+  DV_REQUIRE_PTR(cost);
+  DV_REQUIRE_PTR(disp);
+  DV_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, DV_ERR_SHAPE);
+  return launch_tail(cost, nullptr, disp, unc, B, D, h, w, align_corners, (hipStream_t)stream);
+}
+
+extern "C" int dv_upsample_softmax_uncertainty_f32(const float* cost, const float* disp, float* unc, int B,
+                                                   int D, int h, int w, int align_corners,
+                                                   dv_stream_t stream) {
+  DV_REQUIRE_PTR(cost);
+  DV_REQUIRE_PTR(disp);
+  DV_REQUIRE_PTR(unc);
+  DV_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, DV_ERR_SHAPE);
+  return launch_tail(cost, disp, nullptr, unc, B, D, h, w, align_corners, (hipStream_t)stream);
 }
 
 extern "C" int dv_disparity_regression_f32(const float* prob, float* disp, int B, int D, int H, int W,

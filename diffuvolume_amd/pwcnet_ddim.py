@@ -1,0 +1,565 @@
+"""PCWNet + DiffuVolume (KITTI12 flavour) behind the reference's module API.
+
+Drop-in for ``PWCNet_ddim`` of KITTI12/models/pwcnet_ddim.py:335-758 (eval path): same
+constructor, ``forward(left, right, used, disp, mask) -> ([disp_finetune], [pred3_volume])``,
+``model_predictions`` and ``ddim_sample``; same parameter / buffer names (reference
+``state_dict`` loads with ``strict=True``).
+
+HIP (libdiffuvolume_hip.so): the four group-wise-correlation and concat volumes (KITTI12
+zero-fill flavour), dres0/dres1, ``hourglassup`` and, per DDIM step, the volume filter, the three
+Mish hourglasses, ``classif3``, the align_corners=True trilinear/softmax/regression tail with the
+uncertainty taken about the *refined* disparity, the two-hot re-encoding and the DDIM update.
+PyTorch (MIOpen / ATen): the 2-D feature CNN and the per-step 2-D refinement (bilinear feature
+upsampling, ``warp``, +-24 correlation, ``refinenet3``) -- SURVEY section 8(f) row 2, "next".
+Differences from the ACV flavour: x_T = randn, 3 steps, fill = cumulative
+q_sample(asd), thresholds dif<1 & unc<1, ensemble [0.9,0,0,0.1], Mish activations.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Callable, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib
+from .acv_ddim import ProbVolumeHandle, _bn_of, _plan_cb3, cosine_beta_schedule
+from .head import DynamicHead
+from .profiling import timed
+from .submodule import (ACT_MISH, ACT_NONE, Conv3dPlan, Deconv3dPlan, _dev_f32, build_concat_volume,
+                        build_gwc_volume, upsample_softmax_regress)
+
+NoiseFn = Callable[[str, Tuple[int, ...], torch.dtype], torch.Tensor]
+
+
+class Mish(nn.Module):
+    """x * tanh(softplus(x)) (KITTI12/models/submodule.py:11-18)."""
+
+    def forward(self, x):
+        return x * torch.tanh(F.softplus(x))
+
+
+def _cb2(cin, cout, k, stride, pad, dil):
+    return nn.Sequential(nn.Conv2d(cin, cout, k, stride, dil if dil > 1 else pad, dil, bias=False),
+                         nn.BatchNorm2d(cout))
+
+
+def _cb3(cin, cout, k, stride, pad):
+    return nn.Sequential(nn.Conv3d(cin, cout, k, stride, pad, bias=False), nn.BatchNorm3d(cout))
+
+
+class _Block2d(nn.Module):
+    """BasicBlock with Mish (KITTI12/models/submodule.py:192-215)."""
+
+    def __init__(self, cin, planes, stride, downsample, pad, dil):
+        super().__init__()
+        self.conv1 = nn.Sequential(_cb2(cin, planes, 3, stride, pad, dil), Mish())
+        self.conv2 = _cb2(planes, planes, 3, 1, pad, dil)
+        self.downsample = downsample
+
+    def forward(self, x):
+        y = self.conv2(self.conv1(x))
+        return y + (x if self.downsample is None else self.downsample(x))
+
+
+class _Stacker:
+    inplanes: int
+
+    def _stack(self, planes, blocks, stride, pad, dil):
+        down = None
+        if stride != 1 or self.inplanes != planes:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+        layers = [_Block2d(self.inplanes, planes, stride, down, pad, dil)]
+        self.inplanes = planes
+        layers += [_Block2d(planes, planes, 1, None, pad, dil) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+
+def _head2d(cin, mid, cout):
+    return nn.Sequential(_cb2(cin, mid, 3, 1, 1, 1), Mish(), nn.Conv2d(mid, cout, 1, bias=False))
+
+
+class FeatureExtraction(nn.Module, _Stacker):
+    """Multi-scale 2-D feature CNN (pwcnet_ddim.py:12-128): gw1..gw4 at 1/4..1/32, concat features,
+    refinement feature.  Plain PyTorch."""
+
+    def __init__(self, concat_feature=False, concat_feature_channel=12):
+        super().__init__()
+        self.concat_feature = concat_feature
+        self.inplanes = 32
+        self.firstconv = nn.Sequential(_cb2(3, 32, 3, 2, 1, 1), Mish(), _cb2(32, 32, 3, 1, 1, 1), Mish(),
+                                       _cb2(32, 32, 3, 1, 1, 1), Mish())
+        self.layer1 = self._stack(32, 3, 1, 1, 1)
+        self.layer2 = self._stack(64, 16, 2, 1, 1)
+        self.layer3 = self._stack(128, 3, 1, 1, 1)
+        self.layer4 = self._stack(128, 3, 1, 1, 2)
+        self.layer5 = self._stack(192, 3, 2, 1, 1)
+        self.layer7 = self._stack(256, 3, 2, 1, 1)
+        self.layer9 = self._stack(512, 3, 2, 1, 1)
+        self.gw2 = _head2d(192, 320, 320)
+        self.gw3 = _head2d(256, 320, 320)
+        self.gw4 = _head2d(512, 320, 320)
+        self.layer11 = _head2d(320, 320, 320)
+        self.layer_refine = nn.Sequential(_cb2(320, 128, 3, 1, 1, 1), Mish(), _cb2(128, 32, 1, 1, 0, 1), Mish())
+        if concat_feature:
+            self.lastconv = _head2d(320, 128, concat_feature_channel)
+            self.concat2 = _head2d(192, 128, concat_feature_channel)
+            self.concat3 = _head2d(256, 128, concat_feature_channel)
+            self.concat4 = _head2d(512, 128, concat_feature_channel)
+
+    def forward(self, x):
+        x = self.layer1(self.firstconv(x))
+        l2 = self.layer2(x)
+        l3 = self.layer3(l2)
+        l4 = self.layer4(l3)
+        l5 = self.layer5(l4)
+        l6 = self.layer7(l5)
+        l7 = self.layer9(l6)
+        fc = torch.cat((l2, l3, l4), dim=1)
+        out = {"gw1": self.layer11(fc), "gw2": self.gw2(l5), "gw3": self.gw3(l6), "gw4": self.gw4(l7)}
+        if self.concat_feature:
+            out.update(concat_feature1=self.lastconv(fc), finetune_feature=self.layer_refine(fc),
+                       concat_feature2=self.concat2(l5), concat_feature3=self.concat3(l6),
+                       concat_feature4=self.concat4(l7))
+        return out
+
+
+class RefineNet(nn.Module, _Stacker):
+    """refinenet_version3 (pwcnet_ddim.py:251-306): dilated 2-D residual stack -> disparity residual."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.inplanes = 128
+        self.conv1 = nn.Sequential(_cb2(in_channels, 128, 3, 1, 1, 1), Mish())
+        self.conv2 = nn.Sequential(_cb2(128, 128, 3, 1, 1, 1), Mish())
+        self.conv3 = nn.Sequential(_cb2(128, 128, 3, 1, 2, 2), Mish())
+        self.conv4 = nn.Sequential(_cb2(128, 128, 3, 1, 4, 4), Mish())
+        self.conv5 = self._stack(96, 1, 1, 1, 8)
+        self.conv6 = self._stack(64, 1, 1, 1, 16)
+        self.conv7 = self._stack(32, 1, 1, 1, 1)
+        self.conv8 = nn.Conv2d(32, 1, 3, 1, 1, bias=False)
+
+    def forward(self, x, disp):
+        for m in (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5, self.conv6, self.conv7, self.conv8):
+            x = m(x)
+        return disp + x
+
+
+class HourglassUp(nn.Module):
+    """Parameters of hourglassup (pwcnet_ddim.py:131-205): fuses the 1/8, 1/16, 1/32 volumes."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.conv1 = nn.Conv3d(c, 2 * c, 3, 2, 1, bias=False)
+        self.conv2 = nn.Sequential(_cb3(2 * c, 2 * c, 3, 1, 1), Mish())
+        self.conv3 = nn.Conv3d(2 * c, 4 * c, 3, 2, 1, bias=False)
+        self.conv4 = nn.Sequential(_cb3(4 * c, 4 * c, 3, 1, 1), Mish())
+        self.conv5 = nn.Conv3d(4 * c, 4 * c, 3, 2, 1, bias=False)
+        self.conv6 = nn.Sequential(_cb3(4 * c, 4 * c, 3, 1, 1), Mish())
+        self.conv7 = nn.Sequential(nn.ConvTranspose3d(4 * c, 4 * c, 3, padding=1, output_padding=1, stride=2, bias=False),
+                                   nn.BatchNorm3d(4 * c))
+        self.conv8 = nn.Sequential(nn.ConvTranspose3d(4 * c, 2 * c, 3, padding=1, output_padding=1, stride=2, bias=False),
+                                   nn.BatchNorm3d(2 * c))
+        self.conv9 = nn.Sequential(nn.ConvTranspose3d(2 * c, c, 3, padding=1, output_padding=1, stride=2, bias=False),
+                                   nn.BatchNorm3d(c))
+        self.combine1 = nn.Sequential(_cb3(4 * c, 2 * c, 3, 1, 1), Mish())
+        self.combine2 = nn.Sequential(_cb3(6 * c, 4 * c, 3, 1, 1), Mish())
+        self.combine3 = nn.Sequential(_cb3(6 * c, 4 * c, 3, 1, 1), Mish())
+        self.redir1 = _cb3(c, c, 1, 1, 0)
+        self.redir2 = _cb3(2 * c, 2 * c, 1, 1, 0)
+        self.redir3 = _cb3(4 * c, 4 * c, 1, 1, 0)
+
+
+class Hourglass(nn.Module):
+    """Parameters of the Mish hourglass (pwcnet_ddim.py:208-248): no bottleneck attention."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.conv1 = nn.Sequential(_cb3(c, 2 * c, 3, 2, 1), Mish())
+        self.conv2 = nn.Sequential(_cb3(2 * c, 2 * c, 3, 1, 1), Mish())
+        self.conv3 = nn.Sequential(_cb3(2 * c, 4 * c, 3, 2, 1), Mish())
+        self.conv4 = nn.Sequential(_cb3(4 * c, 4 * c, 3, 1, 1), Mish())
+        self.conv5 = nn.Sequential(nn.ConvTranspose3d(4 * c, 2 * c, 3, padding=1, output_padding=1, stride=2, bias=False),
+                                   nn.BatchNorm3d(2 * c))
+        self.conv6 = nn.Sequential(nn.ConvTranspose3d(2 * c, c, 3, padding=1, output_padding=1, stride=2, bias=False),
+                                   nn.BatchNorm3d(c))
+        self.redir1 = _cb3(c, c, 1, 1, 0)
+        self.redir2 = _cb3(2 * c, 2 * c, 1, 1, 0)
+
+
+# ---- prepared hot-path layers ---------------------------------------------------------------------
+def _deconv_plan(seq, act):
+    return Deconv3dPlan(seq[0].weight, _bn_of(seq[1]), act=act, eps=seq[1].eps)
+
+
+class _HourglassPlan:
+    def __init__(self, hg: Hourglass):
+        self.conv1 = _plan_cb3(hg.conv1[0], 2, ACT_MISH)
+        self.conv2 = _plan_cb3(hg.conv2[0], 1, ACT_MISH)
+        self.conv3 = _plan_cb3(hg.conv3[0], 2, ACT_MISH)
+        self.conv4 = _plan_cb3(hg.conv4[0], 1, ACT_MISH)
+        self.conv5 = _deconv_plan(hg.conv5, ACT_MISH)
+        self.conv6 = _deconv_plan(hg.conv6, ACT_MISH)
+        self.redir1 = _plan_cb3(hg.redir1, 1, ACT_NONE)
+        self.redir2 = _plan_cb3(hg.redir2, 1, ACT_NONE)
+
+    def __call__(self, x, in_scale=None):
+        """``in_scale`` is the [0,1] volume filter: the reference feeds ``volume * noise`` to conv1 AND to
+        redir1 (pwcnet_ddim.py:472-474, :245), so both take the prologue."""
+        c1 = self.conv1(x, in_scale=in_scale)
+        c2 = self.conv2(c1)
+        c4 = self.conv4(self.conv3(c2))
+        c5 = self.conv5(c4, residual=self.redir2(c2))                       # FMish(deconv + redir2)
+        return self.conv6(c5, residual=self.redir1(x, in_scale=in_scale))   # FMish(deconv + redir1)
+
+
+class _HourglassUpPlan:
+    def __init__(self, m: HourglassUp):
+        self.conv1 = Conv3dPlan(m.conv1.weight, None, stride=2, act=ACT_NONE)
+        self.conv3 = Conv3dPlan(m.conv3.weight, None, stride=2, act=ACT_NONE)
+        self.conv5 = Conv3dPlan(m.conv5.weight, None, stride=2, act=ACT_NONE)
+        self.conv2 = _plan_cb3(m.conv2[0], 1, ACT_MISH)
+        self.conv4 = _plan_cb3(m.conv4[0], 1, ACT_MISH)
+        self.conv6 = _plan_cb3(m.conv6[0], 1, ACT_MISH)
+        self.combine1 = _plan_cb3(m.combine1[0], 1, ACT_MISH)
+        self.combine2 = _plan_cb3(m.combine2[0], 1, ACT_MISH)
+        self.combine3 = _plan_cb3(m.combine3[0], 1, ACT_MISH)
+        self.conv7 = _deconv_plan(m.conv7, ACT_MISH)
+        self.conv8 = _deconv_plan(m.conv8, ACT_MISH)
+        self.conv9 = _deconv_plan(m.conv9, ACT_MISH)
+        self.redir1 = _plan_cb3(m.redir1, 1, ACT_NONE)
+        self.redir2 = _plan_cb3(m.redir2, 1, ACT_NONE)
+        self.redir3 = _plan_cb3(m.redir3, 1, ACT_NONE)
+
+    def __call__(self, x, f4, f5, f6):
+        c1 = self.combine1(torch.cat((self.conv1(x), f4), dim=1))
+        c2 = self.conv2(c1)
+        c3 = self.combine2(torch.cat((self.conv3(c2), f5), dim=1))
+        c4 = self.conv4(c3)
+        c5 = self.combine3(torch.cat((self.conv5(c4), f6), dim=1))
+        c6 = self.conv6(c5)
+        c7 = self.conv7(c6, residual=self.redir3(c4))
+        c8 = self.conv8(c7, residual=self.redir2(c2))
+        return self.conv9(c8, residual=self.redir1(x))
+
+
+class _PairPlan:
+    def __init__(self, seq, act_last):
+        self.a = _plan_cb3(seq[0], 1, ACT_MISH)
+        last = seq[2]
+        self.b = _plan_cb3(last, 1, act_last) if isinstance(last, nn.Sequential) else \
+            Conv3dPlan(last.weight, None, stride=1, act=ACT_NONE)
+
+    def __call__(self, x, residual_self=False):
+        return self.b(self.a(x), residual=x if residual_self else None)
+
+
+class _Plans:
+    def __init__(self, m: "PWCNet_ddim"):
+        self.dres0 = _PairPlan(m.dres0, ACT_MISH)
+        self.dres1 = _PairPlan(m.dres1, ACT_NONE)
+        self.combine1 = _HourglassUpPlan(m.combine1)
+        self.dres2, self.dres3, self.dres4 = (_HourglassPlan(h) for h in (m.dres2, m.dres3, m.dres4))
+        self.classif3 = _PairPlan(m.classif3, ACT_NONE)
+        ac = m.alphas_cumprod.detach().double().cpu()
+        self.alphas_cumprod = ac
+        self.sqrt_ac, self.sqrt_1mac = torch.sqrt(ac), torch.sqrt(1.0 - ac)
+        self.sqrt_recip, self.sqrt_recipm1 = torch.sqrt(1.0 / ac), torch.sqrt(1.0 / ac - 1)
+
+
+def groupwise_corr_pm(ref: torch.Tensor, tgt: torch.Tensor, maxdisp: int) -> torch.Tensor:
+    """build_corrleation_volume(ref, tgt, maxdisp, 1) squeezed (KITTI12/models/submodule.py:121-135):
+    mean over channels of ref(x) * tgt(x - i) for i >= 0; for i < 0 the reference's slices pair the first
+    |i| columns of ref with the last |i| columns of tgt -- kept literally.  [B, 2*maxdisp+1, H, W]."""
+    b, c, h, w = ref.shape
+    out = ref.new_zeros(b, 2 * maxdisp + 1, h, w)
+    for i in range(-maxdisp, maxdisp + 1):
+        if i > 0:
+            out[:, i + maxdisp, :, i:] = (ref[..., i:] * tgt[..., :-i]).mean(dim=1)
+        elif i < 0:   # as written in the reference: `[:-i]` (first |i| columns) against `[i:]` (last |i| columns)
+            out[:, i + maxdisp, :, :-i] = (ref[..., :-i] * tgt[..., i:]).mean(dim=1)
+        else:
+            out[:, maxdisp] = (ref * tgt).mean(dim=1)
+    return out
+
+
+def warp(x: torch.Tensor, disp: torch.Tensor) -> torch.Tensor:
+    """warp(right, disp) (KITTI12/models/submodule.py:137-176): sample the right features at x - disp
+    (grid normalised with W-1 but sampled with grid_sample's default align_corners=False, as the
+    reference does) and zero everything the validity mask does not fully cover."""
+    b, c, h, w = x.shape
+    xx = torch.arange(0, w, device=x.device, dtype=torch.float32).view(1, 1, 1, w).expand(b, 1, h, w)
+    yy = torch.arange(0, h, device=x.device, dtype=torch.float32).view(1, 1, h, 1).expand(b, 1, h, w)
+    gx = 2.0 * (xx - disp) / max(w - 1, 1) - 1.0
+    gy = 2.0 * yy / max(h - 1, 1) - 1.0
+    grid = torch.cat((gx, gy), 1).permute(0, 2, 3, 1)
+    out = F.grid_sample(x, grid)
+    mask = F.grid_sample(torch.ones_like(x), grid)
+    mask = torch.where(mask < 0.999, torch.zeros_like(mask), torch.ones_like(mask))
+    return out * mask
+
+
+class PWCNet_ddim(nn.Module):
+    def __init__(self, maxdisp: int, use_concat_volume: bool = True, sampling_timesteps: int = 3,
+                 ensemble_cof: Optional[Sequence[float]] = None):
+        super().__init__()
+        if maxdisp != 192:
+            raise ValueError("PWCNet_ddim is defined for maxdisp == 192 (hard-coded 48 / 192 in the reference)")
+        self.maxdisp, self.use_concat_volume, self.num_groups = maxdisp, use_concat_volume, 40
+        self.scale, self.num_timesteps, self.sampling_timesteps = 1.0, 1000, sampling_timesteps
+        self.ddim_sampling_eta, self.renewal, self.use_ensemble = 1.0, True, True
+        if ensemble_cof is None:
+            if sampling_timesteps != 3:
+                raise ValueError("give ensemble_cof (S+1 weights) when sampling_timesteps != 3")
+            ensemble_cof = (0.9, 0.0, 0.0, 0.1)                       # pwcnet_ddim.py:599
+        if len(ensemble_cof) != sampling_timesteps + 1:
+            raise ValueError("ensemble_cof needs sampling_timesteps + 1 entries")
+        self.ensemble_cof = tuple(float(c) for c in ensemble_cof)
+        self.dif_threshold, self.unc_threshold = 1.0, 1.0            # :571-572 (the last step's <2 mask is unused)
+
+        betas = cosine_beta_schedule(self.num_timesteps)
+        alphas = 1.0 - betas
+        ac = torch.cumprod(alphas, dim=0)
+        ac_prev = F.pad(ac[:-1], (1, 0), value=1.0)
+        post_var = betas * (1.0 - ac_prev) / (1.0 - ac)
+        for name, val in (("betas", betas), ("alphas_cumprod", ac), ("alphas_cumprod_prev", ac_prev),
+                          ("sqrt_alphas_cumprod", torch.sqrt(ac)),
+                          ("sqrt_one_minus_alphas_cumprod", torch.sqrt(1.0 - ac)),
+                          ("log_one_minus_alphas_cumprod", torch.log(1.0 - ac)),
+                          ("sqrt_recip_alphas_cumprod", torch.sqrt(1.0 / ac)),
+                          ("sqrt_recipm1_alphas_cumprod", torch.sqrt(1.0 / ac - 1)),
+                          ("posterior_variance", post_var),
+                          ("posterior_log_variance_clipped", torch.log(post_var.clamp(min=1e-20))),
+                          ("posterior_mean_coef1", betas * torch.sqrt(ac_prev) / (1.0 - ac)),
+                          ("posterior_mean_coef2", (1.0 - ac_prev) * torch.sqrt(alphas) / (1.0 - ac))):
+            self.register_buffer(name, val)
+
+        self.concat_channels = 12 if use_concat_volume else 0
+        self.feature_extraction = FeatureExtraction(use_concat_volume, 12)
+        cin = self.num_groups + 2 * self.concat_channels
+        self.dres0 = nn.Sequential(_cb3(cin, 32, 3, 1, 1), Mish(), _cb3(32, 32, 3, 1, 1), Mish())
+        self.dres1 = nn.Sequential(_cb3(32, 32, 3, 1, 1), Mish(), _cb3(32, 32, 3, 1, 1))
+        self.combine1 = HourglassUp(32)
+        self.time_embedding = DynamicHead(d_model=48)
+        self.dres2, self.dres3, self.dres4 = Hourglass(32), Hourglass(32), Hourglass(32)
+        for i in range(5):
+            setattr(self, f"classif{i}", nn.Sequential(_cb3(32, 32, 3, 1, 1), Mish(), nn.Conv3d(32, 1, 3, 1, 1, bias=False)))
+        self.refinenet3 = RefineNet(146)
+        self.dispupsample = nn.Sequential(_cb2(1, 32, 1, 1, 0, 1), Mish())
+        for m in self.modules():                                     # pwcnet_ddim.py:433-447
+            if isinstance(m, (nn.Conv2d, nn.Conv3d)) and not isinstance(m, nn.ConvTranspose3d):
+                n = m.out_channels
+                for k in m.kernel_size:
+                    n *= k
+                m.weight.data.normal_(0, math.sqrt(2.0 / n))
+            elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d)):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+            elif isinstance(m, nn.Linear):
+                m.bias.data.zero_()
+        self._plans: Optional[_Plans] = None
+
+    # ---- plan cache ---------------------------------------------------------------------------------
+    def _apply(self, fn, *a, **k):
+        self._plans = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._plans = None
+        return super().load_state_dict(*a, **k)
+
+    def train(self, mode: bool = True):
+        self._plans = None
+        return super().train(mode)
+
+    def prepare(self) -> _Plans:
+        if self._plans is None:
+            dev = self.dres0[0][0].weight.device
+            if dev.type != "cuda":
+                raise _lib.DiffuVolumeError("PWCNet_ddim hot path needs the model on the MI355X; no CPU fallback")
+            with torch.no_grad(), torch.cuda.device(dev):
+                self._plans = _Plans(self)
+        return self._plans
+
+    # ---- pieces ---------------------------------------------------------------------------------------
+    def _time_pairs(self):
+        times = torch.linspace(-1, self.num_timesteps - 1, steps=self.sampling_timesteps + 1)
+        times = list(reversed(times.int().tolist()))
+        return list(zip(times[:-1], times[1:]))
+
+    def _filter(self, x_t, t):
+        b, c, h, w = x_t.shape
+        shift = self.time_embedding.shift(t).float().contiguous()
+        lib = _lib.load()
+        x_t = x_t.contiguous()
+        if x_t.dtype == torch.float32:
+            n01 = torch.empty_like(x_t)
+            _lib.check(lib.dv_noise_prepare_f32(x_t.data_ptr(), shift.data_ptr(), n01.data_ptr(), b, c, h * w,
+                                                _lib.stream_ptr()), "dv_noise_prepare_f32")
+            return n01, n01
+        n01 = torch.empty_like(x_t)
+        n01f = torch.empty(x_t.shape, dtype=torch.float32, device=x_t.device)
+        _lib.check(lib.dv_noise_prepare_f64(x_t.data_ptr(), shift.data_ptr(), n01.data_ptr(), n01f.data_ptr(),
+                                            b, c, h * w, _lib.stream_ptr()), "dv_noise_prepare_f64")
+        return n01, n01f
+
+    def _aggregate(self, volume, n01f):
+        """pwcnet_ddim.py:472-477: (volume * filter) -> dres2 -> dres3 -> dres4 -> classif3."""
+        p = self.prepare()
+        return p.classif3(p.dres4(p.dres3(p.dres2(volume, in_scale=n01f))))
+
+    def _refine(self, pred3, features_left, features_right):
+        """pwcnet_ddim.py:486-502 (2-D, PyTorch): warp the right refinement feature by pred3, +-24
+        correlation, refinenet3 -> disp_finetune [B,H,W]."""
+        hh, ww = pred3.shape[-2:]
+        p3 = pred3.unsqueeze(1)
+        fl = F.interpolate(features_left["finetune_feature"], [hh, ww], mode="bilinear", align_corners=True)
+        fr = F.interpolate(features_right["finetune_feature"], [hh, ww], mode="bilinear", align_corners=True)
+        frw = warp(fr, p3)
+        cv = groupwise_corr_pm(fl, frw, 24)
+        comb = torch.cat((fl - frw, fl, self.dispupsample(p3), p3, cv), dim=1)
+        return self.refinenet3(comb, p3).squeeze(1)
+
+    def _uncertainty_about(self, cost, disp):
+        """sum_k |disp - k| * softmax(upsampled cost)_k with ``disp`` = the refined disparity (:548-552)."""
+        cost = cost[:, 0] if cost.dim() == 5 else cost
+        b, d, h, w = cost.shape
+        unc = torch.empty_like(disp)
+        lib = _lib.load()
+        timed("upsample_softmax_uncertainty", 0.0, 4.0 * (cost.numel() + 2 * disp.numel()),
+              lambda: _lib.check(lib.dv_upsample_softmax_uncertainty_f32(cost.data_ptr(), disp.data_ptr(),
+                                                                         unc.data_ptr(), b, d, h, w, 1,
+                                                                         _lib.stream_ptr()),
+                                 "dv_upsample_softmax_uncertainty_f32"))
+        return unc
+
+    def _step_coef(self, time, time_next, cof):
+        p = self.prepare()
+        k = _lib.DvDdimCoef()
+        k.sqrt_recip_alpha, k.sqrt_recipm1_alpha = float(p.sqrt_recip[time]), float(p.sqrt_recipm1[time])
+        k.dif_thr, k.unc_thr, k.cof = self.dif_threshold, self.unc_threshold, cof
+        k.last = int(time_next < 0)
+        if time_next >= 0:
+            alpha, alpha_next = p.alphas_cumprod[time], p.alphas_cumprod[time_next]
+            sigma = self.ddim_sampling_eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+            k.sigma, k.c = float(sigma), float((1 - alpha_next - sigma ** 2).sqrt())
+            k.sqrt_alpha_next = float(alpha_next.sqrt())
+        return k
+
+    def _ddim_update(self, disp, unc, used, n01, eps, fill, mask, ens, coef, want_pred_noise=False):
+        b, c, h, w = n01.shape
+        dev = disp.device
+        x_start = torch.empty((b, c, h, w), dtype=torch.float32, device=dev)
+        x_next = None if coef.last else torch.empty((b, c, h, w), dtype=torch.float64, device=dev)
+        pred_noise = torch.empty((b, c, h, w), dtype=torch.float64, device=dev) if want_pred_noise else None
+        f32 = n01.dtype == torch.float32
+        eps32 = eps if (eps is not None and eps.dtype == torch.float32) else None
+        eps64 = eps if (eps is not None and eps.dtype == torch.float64) else None
+        _lib.check(_lib.load().dv_ddim_step(disp.data_ptr(), unc.data_ptr(), used.data_ptr(),
+                                            n01.data_ptr() if f32 else 0, 0 if f32 else n01.data_ptr(),
+                                            _lib.ptr(eps32), _lib.ptr(eps64), _lib.ptr(fill), mask.data_ptr(),
+                                            x_start.data_ptr(), _lib.ptr(pred_noise), _lib.ptr(x_next), _lib.ptr(ens),
+                                            b, c, h, w, ctypes.byref(coef), _lib.stream_ptr()), "dv_ddim_step")
+        return x_start, x_next, pred_noise
+
+    def _predict(self, volume, img, t, features_left, features_right):
+        n01, n01f = self._filter(img, t)
+        cost = self._aggregate(volume, n01f)
+        pred3, _ = upsample_softmax_regress(cost, want_uncertainty=False, align_corners=True)
+        disp = self._refine(pred3, features_left, features_right).contiguous()
+        unc = self._uncertainty_about(cost, disp)
+        return n01, cost, disp, unc
+
+    # ---- reference API ---------------------------------------------------------------------------------
+    @torch.no_grad()
+    def model_predictions(self, volume, noise, t, features_left, features_right):
+        """pwcnet_ddim.py:466-528 -> (pred_noise fp64, x_start fp32, disp_finetune [B,H,W], ProbVolumeHandle)."""
+        volume = _dev_f32(volume, "volume")
+        b, _, d, h, w = volume.shape
+        with torch.cuda.device(volume.device):
+            n01, cost, disp, unc = self._predict(volume, noise, t, features_left, features_right)
+            coef = self._step_coef(int(t.reshape(-1)[0]), -1, 0.0)
+            mask = torch.zeros((b, h, w), dtype=torch.float32, device=volume.device)
+            x_start, _, pred_noise = self._ddim_update(disp, unc, disp, n01, None, None, mask, None, coef, True)
+        return pred_noise, x_start, disp, ProbVolumeHandle(cost, unc, self.maxdisp, align_corners=True)
+
+    @torch.no_grad()
+    def ddim_sample(self, volume, used, asd, features_left, features_right, noise: Optional[NoiseFn] = None,
+                    generator: Optional[torch.Generator] = None):
+        """pwcnet_ddim.py:530-602.  Random draws in reference order: 'x_T' (torch.randn, :541), then per
+        non-final step 'eps' (randn_like(img), :585) and 'q' (randn_like(asd) inside q_sample, :590)."""
+        volume = _dev_f32(volume, "volume")
+        used = _dev_f32(used, "used")
+        b, _, d, h, w = volume.shape
+        dev = volume.device
+        p = self.prepare()
+
+        def draw(kind, shape, dtype):
+            if noise is not None:
+                return noise(kind, shape, dtype).to(device=dev, dtype=dtype).contiguous()
+            return torch.randn(shape, device=dev, dtype=dtype, generator=generator)
+
+        with torch.cuda.device(dev):
+            img = draw("x_T", (b, 48, h, w), torch.float32)
+            asd = asd.to(dev)
+            final = [used]
+            mask = torch.zeros((b, h, w), dtype=torch.float32, device=dev)
+            ens = used * self.ensemble_cof[0]
+            handle = None
+            for i, (time, time_next) in enumerate(self._time_pairs()):
+                t = torch.full((b,), time, device=dev, dtype=torch.long)
+                n01, cost, disp, unc = self._predict(volume, img, t, features_left, features_right)
+                handle = ProbVolumeHandle(cost, unc, self.maxdisp, align_corners=True)
+                final.append(disp)
+                coef = self._step_coef(time, time_next, self.ensemble_cof[i + 1])
+                eps = fill = None
+                if time_next >= 0:
+                    eps = draw("eps", tuple(img.shape), img.dtype)
+                    # asd = q_sample(asd, t): float64 from the first step on (float64 schedule buffers)
+                    asd = p.sqrt_ac[time].item() * asd.double() + p.sqrt_1mac[time].item() * draw("q", tuple(asd.shape), asd.dtype).double()
+                    fill = asd.contiguous()
+                # (the last step's mask is never read again: the reference only builds the unused mask_final there)
+                x_start, x_next, _ = self._ddim_update(disp, unc, used, n01, eps, fill, mask, ens, coef)
+                img = x_start if time_next < 0 else x_next
+        if self.use_ensemble:
+            return ens, handle
+        return final[-1], handle
+
+    @torch.no_grad()
+    def encode_disparity(self, disp):
+        disp = _dev_f32(disp, "disp")
+        b, h, w = disp.shape[0], disp.shape[-2], disp.shape[-1]
+        x = torch.empty((b, 48, h, w), dtype=torch.float32, device=disp.device)
+        with torch.cuda.device(disp.device):
+            _lib.check(_lib.load().dv_encode_two_hot_f32(disp.data_ptr(), x.data_ptr(), b, 48, h * w,
+                                                         _lib.stream_ptr()), "dv_encode_two_hot_f32")
+        return x
+
+    @torch.no_grad()
+    def fused_volume(self, fl, fr):
+        """pwcnet_ddim.py:608-641: four gwc(+concat) volumes -> dres0/dres1 -> hourglassup -> `combine`."""
+        p = self.prepare()
+        vols = []
+        for i, div in enumerate((4, 8, 16, 32), start=1):
+            v = build_gwc_volume(fl[f"gw{i}"], fr[f"gw{i}"], self.maxdisp // div, self.num_groups)
+            if self.use_concat_volume:
+                cv = build_concat_volume(fl[f"concat_feature{i}"], fr[f"concat_feature{i}"], self.maxdisp // div,
+                                         zero_left=True)
+                v = torch.cat((v, cv), 1)
+            vols.append(v)
+        cost0 = p.dres0(vols[0])
+        cost0 = p.dres1(cost0, residual_self=True)
+        return p.combine1(cost0, vols[1], vols[2], vols[3])
+
+    def forward(self, left, right, used, disp, mask=None):
+        if self.training:
+            raise NotImplementedError("the MI355X DiffuVolume path is inference-only (model.eval())")
+        with torch.no_grad():
+            fl = self.feature_extraction(left)
+            fr = self.feature_extraction(right)
+            combine = self.fused_volume(fl, fr)
+            x_T = self.encode_disparity(disp)
+            disp_finetune, handle = self.ddim_sample(combine, used, x_T, fl, fr)
+        return [disp_finetune], [handle]

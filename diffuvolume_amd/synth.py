@@ -18,13 +18,14 @@ def _gen(seed: int, key: str) -> torch.Generator:
     return g
 
 
-def synth_state_dict(template: Mapping[str, torch.Tensor], seed: int = 0,
-                     logit_gain: float = 1.0) -> Dict[str, torch.Tensor]:
+def synth_state_dict(template: Mapping[str, torch.Tensor], seed: int = 0, logit_gain: float = 1.0,
+                     scale: Mapping[str, float] | None = None) -> Dict[str, torch.Tensor]:
     """Random but well-conditioned values for every entry of ``template`` (a state_dict):
     conv weights ~ N(0, sqrt(2/(k^3*Cout))) as the reference initialises them
     (acv_ddim.py:224-238), BatchNorm with NON-trivial affine and running statistics,
     xavier-uniform Linear weights.  float64 schedule buffers are kept.  ``logit_gain``
-    scales the single-channel classifier heads (sharper or flatter softmax)."""
+    scales the single-channel classifier heads (sharper or flatter softmax); ``scale`` multiplies
+    named tensors."""
     keys = set(template.keys())
     out: Dict[str, torch.Tensor] = {}
     for key, ref in template.items():
@@ -59,6 +60,8 @@ def synth_state_dict(template: Mapping[str, torch.Tensor], seed: int = 0,
             out[key] = torch.randn(shape, generator=g) * 0.02
         else:
             out[key] = torch.randn(shape, generator=g) * 0.1
+        if scale and key in scale:
+            out[key] = out[key] * scale[key]       # e.g. tame an untrained residual head
         out[key] = out[key].to(ref.dtype)
     return out
 
@@ -104,11 +107,12 @@ class NoiseTape:
 
     def __init__(self, seed: int):
         self.seed = seed
-        self.count = {"eps": 0, "fill": 0}
+        self.count = {}
 
     def __call__(self, kind: str, shape, dtype) -> torch.Tensor:
-        k = self.count[kind]
+        """kind 'fill' is uniform [0,1); every other kind ('eps', 'x_T', 'q', ...) is standard normal."""
+        k = self.count.get(kind, 0)
         self.count[kind] = k + 1
         g = _gen(self.seed, f"{kind}{k}")
-        fn = torch.randn if kind == "eps" else torch.rand
+        fn = torch.rand if kind == "fill" else torch.randn
         return fn(tuple(shape), generator=g, dtype=torch.float64).to(dtype)

@@ -112,6 +112,12 @@ int dv_window_attn3d_f32(const float* x, const float* qkv_w /*[3C,C]*/, const fl
 int dv_upsample_softmax_regress_f32(const float* cost, float* disp, float* unc,
                                     int B, int D, int h, int w, int align_corners, dv_stream_t stream);
 
+/* Uncertainty about an externally supplied disparity (KITTI12: the 2-D-refined `disp_finetune`,
+ * pwcnet_ddim.py:548-552): unc = sum_k |disp - k| * softmax(trilinear(cost))_k.
+ * cost [B,D,h,w], disp [B,4h,4w] (input) -> unc [B,4h,4w]. */
+int dv_upsample_softmax_uncertainty_f32(const float* cost, const float* disp, float* unc,
+                                        int B, int D, int h, int w, int align_corners, dv_stream_t stream);
+
 /* disparity_regression on a materialised probability volume (submodule.py:173-177):
  * prob [B,D,H,W] -> disp [B,H,W]. */
 int dv_disparity_regression_f32(const float* prob, float* disp, int B, int D, int H, int W,

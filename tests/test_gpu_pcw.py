@@ -1,0 +1,121 @@
+"""KITTI12 flavour (PCWNet + DiffuVolume) on the HIP path vs the reference's golden vectors and the oracle."""
+import pytest
+import torch
+
+from conftest import load_golden
+from diffuvolume_amd.synth import NoiseTape, _gen, synth_state_dict, synth_stereo_batch
+from oracle import pcw_oracle as P
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(t):
+    return t.to(DEV)
+
+
+def rel_err(a, b):
+    return float((a.cpu().double() - b.double()).abs().max() / b.double().abs().max().clamp(min=1e-30))
+
+
+@pytest.fixture(scope="module")
+def pcw_sd():
+    from diffuvolume_amd.pwcnet_ddim import PWCNet_ddim
+    return synth_state_dict(PWCNet_ddim(192, True).state_dict(), seed=2, logit_gain=8.0,
+                            scale={"refinenet3.conv8.weight": 0.002})
+
+
+@pytest.fixture(scope="module")
+def model(pcw_sd):
+    from diffuvolume_amd.pwcnet_ddim import PWCNet_ddim
+    m = PWCNet_ddim(192, True)
+    m.load_state_dict(pcw_sd, strict=True)
+    return m.to(DEV).eval()
+
+
+def _inputs(seed, b=1, h=16, w=32):
+    vol = torch.rand(b, 32, 48, h, w, generator=_gen(seed, "vol"))
+    fl = {"finetune_feature": torch.randn(b, 32, h, w, generator=_gen(seed, "fl"))}
+    fr = {"finetune_feature": torch.randn(b, 32, h, w, generator=_gen(seed, "fr"))}
+    return vol, fl, fr
+
+
+def _d(feats):
+    return {k: dev(v) for k, v in feats.items()}
+
+
+def test_mish_hourglass_and_hourglassup_golden():
+    from diffuvolume_amd.pwcnet_ddim import Hourglass, HourglassUp, _HourglassPlan, _HourglassUpPlan
+    g = load_golden("pcw_layers")
+    hg = Hourglass(32)
+    hg.load_state_dict(synth_state_dict(hg.state_dict(), seed=71))
+    hu = HourglassUp(32)
+    hu.load_state_dict(synth_state_dict(hu.state_dict(), seed=72))
+    with torch.no_grad():
+        y = _HourglassPlan(hg.to(DEV).eval())(dev(g["hg_x"]))
+        assert rel_err(y, g["hg_y"]) < 2e-5
+        yu = _HourglassUpPlan(hu.to(DEV).eval())(dev(g["hu_x"]), dev(g["hu_f4"]), dev(g["hu_f5"]), dev(g["hu_f6"]))
+        assert rel_err(yu, g["hu_y"]) < 2e-5
+
+
+def test_uncertainty_about_external_disparity():
+    from diffuvolume_amd import _lib
+    from oracle import acv_oracle as A
+    cost = torch.randn(1, 1, 48, 6, 8, generator=_gen(75, "c")) * 4
+    disp_ref, prob = A.upsample_softmax_regress(cost, 192, align_corners=True)
+    other = disp_ref + torch.randn(disp_ref.shape, generator=_gen(75, "o")) * 3
+    unc_ref = A.disparity_uncertainty(other, prob)
+    unc = torch.empty_like(other, device=DEV)
+    c, o = dev(cost[:, 0].contiguous()), dev(other.contiguous())
+    _lib.check(_lib.load().dv_upsample_softmax_uncertainty_f32(c.data_ptr(), o.data_ptr(), unc.data_ptr(), 1, 48, 6, 8,
+                                                               1, _lib.stream_ptr()), "unc")
+    torch.testing.assert_close(unc.cpu(), unc_ref, atol=2e-4, rtol=1e-5)
+
+
+def test_model_predictions_golden(model):
+    g = load_golden("pcw_model_predictions")
+    vol, fl, fr = _inputs(g["seed"])
+    pn, xs, disp, handle = model.model_predictions(dev(vol), dev(g["x_t"]), dev(g["t"]), _d(fl), _d(fr))
+    assert pn.dtype == torch.float64 and xs.dtype == torch.float32
+    d = (disp.cpu() - g["disp"]).abs()
+    assert float(d.mean()) < 3e-4 and float(d.flatten().quantile(0.99)) < 5e-3, (float(d.mean()), float(d.max()))
+    assert float((handle.uncertainty.cpu() - g["unc"]).abs().mean()) < 2e-3
+
+
+def test_ddim_sample_golden_and_float64(model, pcw_sd):
+    g = load_golden("pcw_ddim_sample")
+    vol, fl, fr = _inputs(g["seed"])
+    final, _ = model.ddim_sample(dev(vol), dev(g["used"]), dev(g["asd"]), _d(fl), _d(fr), noise=NoiseTape(g["tape_seed"]))
+    d = (final.cpu() - g["final"]).abs()
+    assert float(d.median()) < 1e-4, float(d.median())
+    # HIP vs fp32 oracle, both against a float64 run of the oracle (2-D refinement included)
+    sd64 = {k: (v.double() if v.is_floating_point() and not k.startswith("time_embedding") else v) for k, v in pcw_sd.items()}
+    f64 = lambda feats: {k: v.double() for k, v in feats.items()}
+    o32, o64 = P.PCWDiffusionOracle(pcw_sd), P.PCWDiffusionOracle(sd64)
+    ref32, _ = o32.ddim_sample(vol, g["used"], g["asd"], fl, fr, NoiseTape(g["tape_seed"]))
+    ref64, _ = o64.ddim_sample(vol.double(), g["used"].double(), g["asd"], f64(fl), f64(fr), NoiseTape(g["tape_seed"]))
+    e_h = float((final.cpu().double() - ref64).abs().mean())
+    e_o = float((ref32.double() - ref64).abs().mean())
+    assert e_h < 10 * e_o + 2e-4, (e_h, e_o)
+
+
+def test_forward_golden():
+    """Whole eval forward (2-D CNN in PyTorch + HIP hot path).  The fixture's weights carry calibration
+    factors on the feature heads (untrained residual stacks otherwise reach 1e9), stored with it."""
+    from diffuvolume_amd.pwcnet_ddim import PWCNet_ddim
+    g = load_golden("pcw_forward_eval")
+    scale = {str(k): float(v) for k, v in zip(g["scale_keys"].tolist(), g["scale_vals"].tolist())}
+    model = PWCNet_ddim(192, True)
+    model.load_state_dict(synth_state_dict(model.state_dict(), seed=2, logit_gain=8.0, scale=scale), strict=True)
+    model = model.to(DEV).eval()
+    batch = synth_stereo_batch(1, 64, 128, seed=g["stereo_seed"], shifts=(8,))
+    tape = NoiseTape(g["tape_seed"])
+    keep = model.ddim_sample
+    model.ddim_sample = lambda v, u, a, fl, fr, **kw: keep(v, u, a, fl, fr, noise=tape)
+    try:
+        out, handles = model(dev(batch["left"]), dev(batch["right"]), dev(batch["used"]), dev(batch["disp"]), None)
+    finally:
+        del model.ddim_sample
+    d = (out[0].cpu() - g["pred"]).abs()
+    assert float(d.median()) < 2e-4, float(d.median())
+    assert float(d.mean()) < 2e-2, float(d.mean())

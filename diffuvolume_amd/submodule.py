@@ -22,6 +22,25 @@ __all__ = ["build_gwc_volume", "build_concat_volume", "build_concat_attention_vo
 ACT_NONE, ACT_RELU, ACT_MISH, ACT_LEAKY = 0, 1, 2, 3
 
 
+_CONV_PRECISION = None
+
+
+def set_default_conv_precision(precision=None) -> None:
+    """Override DV_CONV_PRECISION for plans built from now on ('f32', 'f16x3' or None = environment)."""
+    global _CONV_PRECISION
+    if precision not in (None, "f32", "f16x3"):
+        raise ValueError("precision must be 'f32', 'f16x3' or None")
+    _CONV_PRECISION = precision
+
+
+def default_conv_precision() -> str:
+    """'f32' = exact-fp32 MFMA everywhere (default); 'f16x3' = the split-fp16 kernel for the 3x3x3
+    stride-1 layers it covers (csrc/conv3d_f16x3.hip; inputs must stay below 2.6e5 in magnitude).
+    Set with DV_CONV_PRECISION, set_default_conv_precision() or per plan."""
+    import os
+    return _CONV_PRECISION or os.environ.get("DV_CONV_PRECISION", "f32")
+
+
 def _dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name} must be a tensor")
@@ -140,19 +159,31 @@ class Conv3dPlan:
 
     def __init__(self, weight: torch.Tensor, bn: Optional[Tuple[torch.Tensor, ...]] = None,
                  stride: int = 1, act: int = ACT_NONE, bias: Optional[torch.Tensor] = None,
-                 eps: float = 1e-5):
+                 eps: float = 1e-5, precision: Optional[str] = None):
         w = _dev_f32(weight.detach(), "weight")
         self.cout, self.cin, k = w.shape[0], w.shape[1], w.shape[2]
         if tuple(w.shape[2:]) != (k, k, k) or k not in (1, 3):
             raise _lib.DiffuVolumeError(f"unsupported Conv3d kernel {tuple(w.shape[2:])}")
         self.k, self.stride, self.act = k, stride, act
+        precision = precision or default_conv_precision()
+        if precision not in ("f32", "f16x3"):
+            raise ValueError("precision must be 'f32' (v_mfma_f32_16x16x4_f32) or 'f16x3' (split-fp16 MFMA)")
+        # the split-fp16 kernel covers the 3x3x3 stride-1 layers with up to 32 output channels (2..32)
+        self.split = precision == "f16x3" and k == 3 and stride == 1 and 1 < self.cout <= 32
         lib = _lib.load()
-        n = lib.dv_conv3d_packed_floats(self.cin, self.cout, k)
-        self.wpacked = torch.empty(n, dtype=torch.float32, device=w.device)
         with torch.cuda.device(w.device):
-            _lib.check(lib.dv_conv3d_pack_weights_f32(w.data_ptr(), self.wpacked.data_ptr(), self.cin,
-                                                      self.cout, k, _lib.stream_ptr()),
-                       "dv_conv3d_pack_weights_f32")
+            if self.split:
+                nbytes = lib.dv_conv3d_f16x3_packed_bytes(self.cin, self.cout)
+                self.wpacked = torch.empty(nbytes // 2, dtype=torch.float16, device=w.device)
+                _lib.check(lib.dv_conv3d_f16x3_pack_weights(w.data_ptr(), self.wpacked.data_ptr(), self.cin,
+                                                            self.cout, _lib.stream_ptr()),
+                           "dv_conv3d_f16x3_pack_weights")
+            else:
+                n = lib.dv_conv3d_packed_floats(self.cin, self.cout, k)
+                self.wpacked = torch.empty(n, dtype=torch.float32, device=w.device)
+                _lib.check(lib.dv_conv3d_pack_weights_f32(w.data_ptr(), self.wpacked.data_ptr(), self.cin,
+                                                          self.cout, k, _lib.stream_ptr()),
+                           "dv_conv3d_pack_weights_f32")
         self.scale, self.shift = _fold_bn(bn, bias, self.cout, w.device, eps)
 
     def out_shape(self, shape):
@@ -183,6 +214,16 @@ class Conv3dPlan:
         with torch.cuda.device(x.device):
             nb = 4.0 * (x.numel() + out.numel() + (0 if in_scale is None else in_scale.numel())
                         + (0 if residual is None else residual.numel()))
+            if self.split:
+                timed(f"conv3d_f16x3_co{self.cout}" + ("" if in_scale is None else "_filter"),
+                      2.0 * out.numel() * cin * 27, nb,
+                      lambda: _lib.check(lib.dv_conv3d_f16x3_f32(x.data_ptr(), self.wpacked.data_ptr(),
+                                                                 _lib.ptr(self.scale), _lib.ptr(self.shift),
+                                                                 _lib.ptr(in_scale), _lib.ptr(residual),
+                                                                 out.data_ptr(), b, cin, d, h, w, self.cout,
+                                                                 self.act, _lib.stream_ptr()),
+                                         "dv_conv3d_f16x3_f32"))
+                return out
             timed(f"conv3d_k{self.k}s{self.stride}_co{self.cout}" + ("" if in_scale is None else "_filter"),
                   2.0 * out.numel() * cin * self.k ** 3, nb,
                   lambda: _lib.check(lib.dv_conv3d_f32(x.data_ptr(), self.wpacked.data_ptr(), _lib.ptr(self.scale),

@@ -84,6 +84,16 @@ int dv_conv3d_f32(const float* in, const float* wpacked, const float* ch_scale, 
                   int B, int Cin, int D, int H, int W, int Cout, int k, int stride, int act,
                   dv_stream_t stream);
 
+/* The same 3x3x3 stride-1 layer (Cout <= 32) on the fp16 matrix instruction with every fp32 operand
+ * carried as hi+lo fp16 pairs: x*w ~= hi*hi' + hi*lo' + lo*hi', fp32 accumulate (csrc/conv3d_f16x3.hip).
+ * Split error 2^-22 per operand, below the fp32 accumulation rounding; opt-in (DV_CONV_PRECISION=f16x3). */
+size_t dv_conv3d_f16x3_packed_bytes(int Cin, int Cout);
+int dv_conv3d_f16x3_pack_weights(const float* w /*[Cout,Cin,3,3,3]*/, void* wpacked, int Cin, int Cout,
+                                 dv_stream_t stream);
+int dv_conv3d_f16x3_f32(const float* in, const void* wpacked, const float* ch_scale, const float* ch_bias,
+                        const float* in_scale, const float* residual, float* out,
+                        int B, int Cin, int D, int H, int W, int Cout, int act, dv_stream_t stream);
+
 /* nn.ConvTranspose3d(k=3, stride=2, padding=1, output_padding=1, bias=False) + BN
  * + skip add + activation: acv_ddim.py:74-80 and :91-92.  w [Cin,Cout,3,3,3].
  * in [B,Cin,D,H,W] -> out [B,Cout,2D,2H,2W]. */

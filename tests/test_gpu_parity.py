@@ -390,3 +390,52 @@ def test_igev_geo_filter_lookup_oracle_kitti_size():
     ref = IO.geo_filter_lookup(geo, f1, f2, disp, coords, noisy)
     out = Combined_Geo_Encoding_Volume(dev(f1), dev(f2), dev(geo))(dev(disp), dev(coords), dev(noisy))
     torch.testing.assert_close(out.cpu(), ref, atol=3e-5, rtol=1e-5)
+
+
+# ---------------------------------------------------------------- split-fp16 (hi/lo) MFMA convolution
+@pytest.mark.parametrize("cfg", [(32, 32, (1, 6, 8, 48)), (64, 32, (2, 5, 7, 44)), (40, 32, (1, 4, 4, 32)),
+                                 (32, 16, (1, 3, 9, 30)), (8, 32, (1, 2, 4, 96))])
+def test_conv_f16x3_oracle(cfg):
+    """x*w ~= hi*hi' + hi*lo' + lo*hi' on the fp16 matrix cores must stay at the fp32 bar (1e-5)."""
+    cin, cout, dims = cfg
+    g = _gen(17, str(cfg))
+    x = torch.randn(dims[0], cin, *dims[1:], generator=g) * 3
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5
+    bn = (torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1,
+          torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5)
+    scale = torch.rand(dims[0], *dims[1:], generator=g)
+    res = torch.randn(dims[0], cout, *dims[1:], generator=g)
+    y64 = torch.nn.functional.batch_norm(
+        torch.nn.functional.conv3d(x.double() * scale.unsqueeze(1).double(), w.double(), None, 1, 1),
+        bn[2].double(), bn[3].double(), bn[0].double(), bn[1].double(), False, 0.0, 1e-5)
+    ref = torch.relu(y64 + res.double())
+    bnd = tuple(dev(t) for t in bn)
+    out16 = S.Conv3dPlan(dev(w), bnd, stride=1, act=S.ACT_RELU, precision="f16x3")(dev(x), in_scale=dev(scale), residual=dev(res))
+    out32 = S.Conv3dPlan(dev(w), bnd, stride=1, act=S.ACT_RELU, precision="f32")(dev(x), in_scale=dev(scale), residual=dev(res))
+    e16, e32 = rel_err(out16, ref), rel_err(out32, ref)
+    assert e16 < 1e-5, (e16, e32)
+    assert e16 < 3 * e32 + 1e-7, (e16, e32)      # as close to float64 as the exact-fp32 MFMA kernel
+
+
+def test_ddim_loop_with_split_fp16_convs(acv_state_dict):
+    """The whole 5-step loop with the 3x3x3 stride-1 convs on the split-fp16 MFMA kernel: same bars as
+    the exact-fp32 build (median within 1e-4 px of the reference, distance to float64 comparable)."""
+    from diffuvolume_amd import ACVNet_DDIM
+    S.set_default_conv_precision("f16x3")
+    try:
+        m = ACVNet_DDIM(192, False, False)
+        m.load_state_dict(acv_state_dict, strict=True)
+        m = m.to(DEV).eval()
+        m.prepare()
+        assert m._plans.dres0.b.split and m._plans.dres1.a.split and not m._plans.dres2.conv1.split
+    finally:
+        S.set_default_conv_precision(None)
+    g = load_golden("ddim_sample")
+    vol = _volume(g["vol_seed"])
+    final, stack = m.ddim_sample(dev(vol), dev(g["used"]), dev(g["x_T"]), noise=NoiseTape(g["tape_seed"]))
+    d = (stack.cpu() - g["stack"]).abs()
+    for i in range(1, 6):
+        assert float(d[i].median()) < 1e-4, (i, float(d[i].median()))
+    assert float(d[1].mean()) < 2e-4 and float((d[1] > 1e-3).float().mean()) < 1e-2
+    e_h, e_o, ef_h, ef_o = _loop_errors(m, acv_state_dict, vol, g["used"], g["x_T"], g["tape_seed"])
+    _check_loop(e_h, e_o, ef_h, ef_o)

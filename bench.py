@@ -132,8 +132,8 @@ def main():
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU visible"
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    torch.cuda.set_device(D.device_index(local))
+    device = torch.device("cuda", D.device_index(local))
 
     import diffuvolume_amd as dv
     from diffuvolume_amd import metrics as M

@@ -23,11 +23,18 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+            backend = os.environ.get("DV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(device_index(local))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def device_index(local_rank: int) -> int:
+    """GPU of a local rank.  One process per GPU in production; when a box has fewer GPUs than ranks
+    (plumbing tests of the N>1 path on a 1-GPU box, gloo backend) ranks wrap around."""
+    n = torch.cuda.device_count()
+    return local_rank % n if n > 0 else 0
 
 
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:

@@ -182,10 +182,11 @@ class _Plans:
         self.dres1_att = _ConvPairPlan(m.dres1_att_, relu_last=False)
         self.dres2_att = _HourglassPlan(m.dres2_att_)
         self.classif_att = _ConvPairPlan(m.classif_att_, relu_last=False)
-        ac = m.alphas_cumprod.detach().double().cpu()
-        self.alphas_cumprod = ac
-        self.sqrt_recip = torch.sqrt(1.0 / ac)
-        self.sqrt_recipm1 = torch.sqrt(1.0 / ac - 1)
+        if hasattr(m, "alphas_cumprod"):                       # the origin ACVNet has no diffusion schedule
+            ac = m.alphas_cumprod.detach().double().cpu()
+            self.alphas_cumprod = ac
+            self.sqrt_recip = torch.sqrt(1.0 / ac)
+            self.sqrt_recipm1 = torch.sqrt(1.0 / ac - 1)
 
 
 class ProbVolumeHandle:
@@ -211,7 +212,38 @@ def cosine_beta_schedule(timesteps: int, s: float = 0.008) -> torch.Tensor:
     return torch.clip(1 - (ac[1:] / ac[:-1]), 0, 0.999)
 
 
-class ACVNet_DDIM(nn.Module):
+class _HipPlanMixin(nn.Module):
+    """Plan cache shared by the ACV wrappers: BatchNorm folding / weight repacking happens once per weight
+    set and is redone when parameters move or are reloaded."""
+    _plans = None
+
+    # ---- plan cache: rebuilt when parameters move or are reloaded -----------------------
+    def _apply(self, fn, *args, **kwargs):
+        self._plans = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._plans = None
+        return super().load_state_dict(*args, **kwargs)
+
+    def train(self, mode: bool = True):
+        self._plans = None
+        return super().train(mode)
+
+    def prepare(self) -> _Plans:
+        """Fold BatchNorm and repack weights for the HIP kernels (once per weight set)."""
+        if self._plans is None:
+            dev = self.dres0[0][0].weight.device
+            if dev.type != "cuda":
+                raise _lib.DiffuVolumeError(
+                    "the ACVNet hot path needs the model on the MI355X (model.cuda()); no CPU fallback")
+            with torch.no_grad(), torch.cuda.device(dev):
+                self._plans = _Plans(self)
+        return self._plans
+
+
+
+class ACVNet_DDIM(_HipPlanMixin):
     def __init__(self, maxdisp: int, attn_weights_only: bool = False, freeze_attn_weights: bool = False,
                  sampling_timesteps: int = 5, ensemble_cof: Optional[Sequence[float]] = None):
         super().__init__()
@@ -295,30 +327,6 @@ class ACVNet_DDIM(nn.Module):
                 m.bias.data.zero_()
             elif isinstance(m, nn.Linear):
                 m.bias.data.zero_()
-
-    # ---- plan cache: rebuilt when parameters move or are reloaded -----------------------
-    def _apply(self, fn, *args, **kwargs):
-        self._plans = None
-        return super()._apply(fn, *args, **kwargs)
-
-    def load_state_dict(self, *args, **kwargs):
-        self._plans = None
-        return super().load_state_dict(*args, **kwargs)
-
-    def train(self, mode: bool = True):
-        self._plans = None
-        return super().train(mode)
-
-    def prepare(self) -> _Plans:
-        """Fold BatchNorm and repack weights for the HIP kernels (once per weight set)."""
-        if self._plans is None:
-            dev = self.dres0[0][0].weight.device
-            if dev.type != "cuda":
-                raise _lib.DiffuVolumeError(
-                    "ACVNet_DDIM hot path needs the model on the MI355X (model.cuda()); no CPU fallback")
-            with torch.no_grad(), torch.cuda.device(dev):
-                self._plans = _Plans(self)
-        return self._plans
 
     # ---- pieces of the hot path ----------------------------------------------------------
     def _time_pairs(self) -> List[Tuple[int, int]]:
@@ -487,4 +495,51 @@ class ACVNet_DDIM(nn.Module):
         return [pred]
 
 
-__models__ = {"acvnet_ddim": ACVNet_DDIM}
+class ACVNet(_HipPlanMixin):
+    """The origin network that supplies ``used`` (SceneFlow/models/acv.py:94-260, eval path with
+    attn_weights_only=False): same feature CNN, attention branch, concat volume and aggregation stack as
+    ACVNet_DDIM, run on the same HIP kernels, without the diffusion loop.  ``forward(left, right) -> [pred2]``.
+    Reference ``state_dict`` (561 keys) loads with strict=True."""
+
+    def __init__(self, maxdisp: int, attn_weights_only: bool = False, freeze_attn_weights: bool = False):
+        super().__init__()
+        if maxdisp != 192 or attn_weights_only:
+            raise ValueError("ACVNet on the HIP path: maxdisp == 192 and attn_weights_only == False")
+        self.maxdisp, self.attn_weights_only, self.freeze_attn_weights = maxdisp, attn_weights_only, freeze_attn_weights
+        self.num_groups, self.concat_channels = 40, 32
+        self.feature_extraction = FeatureExtraction()
+        self.concatconv = nn.Sequential(_cb2(320, 128, 3, 1, 1, 1), nn.ReLU(inplace=True),
+                                        nn.Conv2d(128, self.concat_channels, 1, bias=False))
+        self.patch = nn.Conv3d(40, 40, (1, 3, 3), 1, (0, 1, 1), 1, groups=40, bias=False)
+        self.patch_l1 = nn.Conv3d(8, 8, (1, 3, 3), 1, (0, 1, 1), 1, groups=8, bias=False)
+        self.patch_l2 = nn.Conv3d(16, 16, (1, 3, 3), 1, (0, 2, 2), 2, groups=16, bias=False)
+        self.patch_l3 = nn.Conv3d(16, 16, (1, 3, 3), 1, (0, 3, 3), 3, groups=16, bias=False)
+        self.dres1_att_ = nn.Sequential(_cb3(40, 32, 3, 1, 1), nn.ReLU(inplace=True), _cb3(32, 32, 3, 1, 1))
+        self.dres2_att_ = Hourglass(32)
+        self.classif_att_ = ACVNet_DDIM._classifier()
+        self.dres0 = nn.Sequential(_cb3(64, 32, 3, 1, 1), nn.ReLU(inplace=True),
+                                   _cb3(32, 32, 3, 1, 1), nn.ReLU(inplace=True))
+        self.dres1 = nn.Sequential(_cb3(32, 32, 3, 1, 1), nn.ReLU(inplace=True), _cb3(32, 32, 3, 1, 1))
+        self.dres2 = Hourglass(32)
+        self.dres3 = Hourglass(32)
+        self.classif0 = ACVNet_DDIM._classifier()
+        self.classif1 = ACVNet_DDIM._classifier()
+        self.classif2 = ACVNet_DDIM._classifier()
+        ACVNet_DDIM._init_weights(self)
+        self._plans: Optional[_Plans] = None
+
+    attention_concat_volume = ACVNet_DDIM.attention_concat_volume
+    _aggregate = ACVNet_DDIM._aggregate
+
+    def forward(self, left, right):
+        if self.training:
+            raise NotImplementedError("the MI355X path is inference-only (model.eval())")
+        with torch.no_grad():
+            fl = self.feature_extraction(left)["gwc_feature"]
+            fr = self.feature_extraction(right)["gwc_feature"]
+            cost = self._aggregate(self.attention_concat_volume(fl, fr), None)
+            pred2, _ = upsample_softmax_regress(cost, want_uncertainty=False)
+        return [pred2]
+
+
+__models__ = {"acvnet": ACVNet, "acvnet_ddim": ACVNet_DDIM}

@@ -439,3 +439,17 @@ def test_ddim_loop_with_split_fp16_convs(acv_state_dict):
     assert float(d[1].mean()) < 2e-4 and float((d[1] > 1e-3).float().mean()) < 1e-2
     e_h, e_o, ef_h, ef_o = _loop_errors(m, acv_state_dict, vol, g["used"], g["x_T"], g["tape_seed"])
     _check_loop(e_h, e_o, ef_h, ef_o)
+
+
+def test_origin_acvnet_forward_golden():
+    """SceneFlow/models/acv.py eval forward (the network that supplies `used`) on the same HIP kernels."""
+    from diffuvolume_amd import ACVNet
+    g = load_golden("acv_origin_forward")
+    m = ACVNet(192, False, False)
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed=3, logit_gain=8.0), strict=True)
+    m = m.to(DEV).eval()
+    batch = synth_stereo_batch(2, 64, 128, seed=g["stereo_seed"], shifts=(8, 20))
+    pred = m(dev(batch["left"]), dev(batch["right"]))[-1]
+    d = (pred.cpu() - g["pred"]).abs()
+    assert pred.shape == g["pred"].shape
+    assert float(d.median()) < 1e-4 and float(d.mean()) < 1e-3, (float(d.median()), float(d.mean()))

@@ -132,3 +132,14 @@ def test_per_image_metric_rules():
     acc.update({n: torch.tensor(v) for n, v in zip(M.NAMES, (3.0, 0.3, 0.2, 0.3, 0.4))})
     out = acc.reduce()
     assert out["EPE"] == 2.0 and abs(out["D1"] - 0.2) < 1e-7        # AverageMeterDict: mean over batches (fp32 inputs)
+
+
+def test_origin_and_pcw_state_dict_layouts():
+    from diffuvolume_amd import ACVNet, PWCNet_ddim
+    assert len(ACVNet(192).state_dict()) == 561                        # acvnet: no schedule buffers / time MLP
+    pcw = PWCNet_ddim(192, True)
+    sd = pcw.state_dict()
+    assert len(sd) == 905 and sum(p.numel() for p in pcw.parameters()) == 35994800
+    assert tuple(sd["combine1.conv7.0.weight"].shape) == (128, 128, 3, 3, 3)
+    assert pcw._time_pairs() == [(999, 665), (665, 332), (332, -1)]
+    assert sorted(__models__) == ["acvnet", "acvnet_ddim", "pwc_ddimgc"]

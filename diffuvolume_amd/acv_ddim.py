@@ -28,8 +28,13 @@ from torch import nn
 from . import _lib
 from .head import DynamicHead
 from .submodule import (ACT_NONE, ACT_RELU, Conv3dPlan, Deconv3dPlan, _dev_f32,
-                        build_concat_attention_volume, build_gwc_volume, upsample_softmax_regress,
-                        window_attention)
+                        build_concat_attention_volume, build_gwc_volume, check_split_overflow,
+                        default_conv_precision, upsample_softmax_regress, window_attention)
+
+
+def any_split_plan(plans) -> bool:
+    """True if the prepared layers include a split-fp16 convolution (its range guard must be read)."""
+    return plans is not None and getattr(plans.dres0.b, "split", False)
 
 NoiseFn = Callable[[str, Tuple[int, ...], torch.dtype], torch.Tensor]
 
@@ -448,6 +453,8 @@ class ACVNet_DDIM(_HipPlanMixin):
                 x_start, x_next, _ = self._ddim_update(disp, unc, used, n01, eps, fill, mask, ens, coef)
                 img = x_start if time_next < 0 else x_next
         stack = torch.stack(final, dim=0)
+        if any_split_plan(self._plans):
+            check_split_overflow(dev)
         if self.use_ensemble:
             return ens, stack
         return final[-1]
@@ -539,6 +546,8 @@ class ACVNet(_HipPlanMixin):
             fr = self.feature_extraction(right)["gwc_feature"]
             cost = self._aggregate(self.attention_concat_volume(fl, fr), None)
             pred2, _ = upsample_softmax_regress(cost, want_uncertainty=False)
+            if any_split_plan(self._plans):
+                check_split_overflow(pred2.device)
         return [pred2]
 
 

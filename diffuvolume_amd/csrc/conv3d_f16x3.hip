@@ -58,6 +58,7 @@ struct Args {
   const float* in_scale;
   const float* residual;
   float* out;
+  int* overflow;         // set to 1 when an activation leaves the fp16 range (may be null)
   int B, Cin, D, H, W, Cout, Coutp;
   int ntx, nty, ntz, nco;
   int act, vec_store;
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16x3_kernel(Args a) {
       if (e < 2 * W_H8) vw[q] = wsrc[((size_t)part * KB * 4 + sl) * a.Coutp + co0 + n];
     }
   };
+  float vmax = 0.f;   // largest scaled magnitude this thread has split (range guard)
   auto commit = [&]() {
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
@@ -154,6 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16x3_kernel(Args a) {
         // the rounded product for hi -- the empty asm makes v opaque so the two cannot be re-derived.)
         float v = vin[i][cl] * (HAS_SCALE ? scl[i] : kActScale);
         asm volatile("" : "+v"(v));
+        vmax = fmaxf(vmax, fabsf(v));
         const _Float16 h = (_Float16)v;
         hi[cl] = h;
         lo[cl] = (_Float16)(v - (float)h);
@@ -199,6 +202,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16x3_kernel(Args a) {
       }
     }
   }
+
+  // range guard: fp16 tops out at 65504; NaN inputs also trip it (fmaxf ignores NaN, so test v != v via !(<=))
+  if (a.overflow && !(vmax <= 65000.f)) *a.overflow = 1;
 
   // epilogue (as conv3d.hip): descale, BN scale/bias, residual, activation, 16-B stores along x
   const size_t ovol = vol;  // stride 1: output volume == input volume
@@ -280,8 +286,8 @@ extern "C" int dv_conv3d_f16x3_pack_weights(const float* w, void* wpacked, int C
 }
 
 extern "C" int dv_conv3d_f16x3_f32(const float* in, const void* wpacked, const float* ch_scale, const float* ch_bias,
-                                   const float* in_scale, const float* residual, float* out, int B, int Cin, int D,
-                                   int H, int W, int Cout, int act, dv_stream_t stream) {
+                                   const float* in_scale, const float* residual, float* out, int* overflow_flag,
+                                   int B, int Cin, int D, int H, int W, int Cout, int act, dv_stream_t stream) {
   DV_REQUIRE_PTR(in);
   DV_REQUIRE_PTR(wpacked);
   DV_REQUIRE_PTR(out);
@@ -290,7 +296,7 @@ extern "C" int dv_conv3d_f16x3_f32(const float* in, const void* wpacked, const f
   DV_REQUIRE(dv_aligned16(wpacked), DV_ERR_ALIGN);
   Args a;
   a.in = in; a.wpk = (const _Float16*)wpacked; a.ch_scale = ch_scale; a.ch_bias = ch_bias; a.in_scale = in_scale;
-  a.residual = residual; a.out = out;
+  a.residual = residual; a.out = out; a.overflow = overflow_flag;
   a.B = B; a.Cin = Cin; a.D = D; a.H = H; a.W = W; a.Cout = Cout; a.Coutp = pad_to(Cout, COUT);
   a.ntx = (W + TW - 1) / TW; a.nty = (H + TH - 1) / TH; a.ntz = (D + TD - 1) / TD; a.nco = a.Coutp / COUT;
   a.act = act;

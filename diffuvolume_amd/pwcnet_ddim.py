@@ -29,7 +29,7 @@ from .acv_ddim import ProbVolumeHandle, _bn_of, _plan_cb3, cosine_beta_schedule
 from .head import DynamicHead
 from .profiling import timed
 from .submodule import (ACT_MISH, ACT_NONE, Conv3dPlan, Deconv3dPlan, _dev_f32, build_concat_volume,
-                        build_gwc_volume, upsample_softmax_regress)
+                        build_gwc_volume, check_split_overflow, upsample_softmax_regress)
 
 NoiseFn = Callable[[str, Tuple[int, ...], torch.dtype], torch.Tensor]
 
@@ -523,6 +523,8 @@ class PWCNet_ddim(nn.Module):
                 # (the last step's mask is never read again: the reference only builds the unused mask_final there)
                 x_start, x_next, _ = self._ddim_update(disp, unc, used, n01, eps, fill, mask, ens, coef)
                 img = x_start if time_next < 0 else x_next
+        if getattr(p.dres0.b, "split", False):
+            check_split_overflow(dev)
         if self.use_ensemble:
             return ens, handle
         return final[-1], handle

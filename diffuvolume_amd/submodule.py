@@ -33,6 +33,27 @@ def set_default_conv_precision(precision=None) -> None:
     _CONV_PRECISION = precision
 
 
+_OVERFLOW_FLAGS = {}
+
+
+def split_overflow_flag(device) -> torch.Tensor:
+    """Device int32 the split-fp16 conv kernels raise when an activation leaves the fp16 range."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _OVERFLOW_FLAGS:
+        _OVERFLOW_FLAGS[key] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", key))
+    return _OVERFLOW_FLAGS[key]
+
+
+def check_split_overflow(device) -> None:
+    """Raise (after one device sync) if a split-fp16 convolution saw an out-of-range activation since the
+    last check; the wrappers call it before they hand results back."""
+    flag = split_overflow_flag(device)
+    if int(flag.item()) != 0:
+        flag.zero_()
+        raise _lib.DiffuVolumeError("an activation exceeded the split-fp16 range (|x| >= 2.6e5 or NaN): "
+                                    "rebuild the plans with precision='f32' (DV_CONV_PRECISION=f32)")
+
+
 def default_conv_precision() -> str:
     """'f32' = exact-fp32 MFMA everywhere (default); 'f16x3' = the split-fp16 kernel for the 3x3x3
     stride-1 layers it covers (csrc/conv3d_f16x3.hip; inputs must stay below 2.6e5 in magnitude).
@@ -220,7 +241,8 @@ class Conv3dPlan:
                       lambda: _lib.check(lib.dv_conv3d_f16x3_f32(x.data_ptr(), self.wpacked.data_ptr(),
                                                                  _lib.ptr(self.scale), _lib.ptr(self.shift),
                                                                  _lib.ptr(in_scale), _lib.ptr(residual),
-                                                                 out.data_ptr(), b, cin, d, h, w, self.cout,
+                                                                 out.data_ptr(), split_overflow_flag(x.device).data_ptr(),
+                                                                 b, cin, d, h, w, self.cout,
                                                                  self.act, _lib.stream_ptr()),
                                          "dv_conv3d_f16x3_f32"))
                 return out

@@ -86,12 +86,14 @@ int dv_conv3d_f32(const float* in, const float* wpacked, const float* ch_scale, 
 
 /* The same 3x3x3 stride-1 layer (Cout <= 32) on the fp16 matrix instruction with every fp32 operand
  * carried as hi+lo fp16 pairs: x*w ~= hi*hi' + hi*lo' + lo*hi', fp32 accumulate (csrc/conv3d_f16x3.hip).
- * Split error 2^-22 per operand, below the fp32 accumulation rounding; opt-in (DV_CONV_PRECISION=f16x3). */
+ * Split error 2^-22 per operand, below the fp32 accumulation rounding; opt-in (DV_CONV_PRECISION=f16x3).
+ * Activations must stay below 2.6e5 in magnitude (fp16 range after the 2^-2 pre-scale): if one does not,
+ * or is NaN, *overflow_flag (device int, may be NULL) is set to 1 and the output is not to be trusted. */
 size_t dv_conv3d_f16x3_packed_bytes(int Cin, int Cout);
 int dv_conv3d_f16x3_pack_weights(const float* w /*[Cout,Cin,3,3,3]*/, void* wpacked, int Cin, int Cout,
                                  dv_stream_t stream);
 int dv_conv3d_f16x3_f32(const float* in, const void* wpacked, const float* ch_scale, const float* ch_bias,
-                        const float* in_scale, const float* residual, float* out,
+                        const float* in_scale, const float* residual, float* out, int* overflow_flag,
                         int B, int Cin, int D, int H, int W, int Cout, int act, dv_stream_t stream);
 
 /* nn.ConvTranspose3d(k=3, stride=2, padding=1, output_padding=1, bias=False) + BN

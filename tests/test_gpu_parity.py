@@ -453,3 +453,20 @@ def test_origin_acvnet_forward_golden():
     d = (pred.cpu() - g["pred"]).abs()
     assert pred.shape == g["pred"].shape
     assert float(d.median()) < 1e-4 and float(d.mean()) < 1e-3, (float(d.median()), float(d.mean()))
+
+
+def test_split_fp16_range_guard():
+    """Activations beyond the fp16 range must not pass silently: the kernel raises a device flag and the
+    wrapper turns it into an error (no quiet garbage, no quiet fallback)."""
+    from diffuvolume_amd import DiffuVolumeError
+    w = torch.randn(32, 32, 3, 3, 3) * 0.05
+    plan = S.Conv3dPlan(dev(w), None, 1, S.ACT_NONE, precision="f16x3")
+    x = torch.randn(1, 32, 2, 4, 48)
+    S.split_overflow_flag(DEV).zero_()
+    plan(dev(x))
+    S.check_split_overflow(DEV)                       # in range: no error
+    x[0, 3, 1, 2, 7] = 1e6
+    plan(dev(x))
+    with pytest.raises(DiffuVolumeError):
+        S.check_split_overflow(DEV)
+    S.check_split_overflow(DEV)                       # flag was cleared

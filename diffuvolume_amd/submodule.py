@@ -189,8 +189,9 @@ class Conv3dPlan:
         precision = precision or default_conv_precision()
         if precision not in ("f32", "f16x3"):
             raise ValueError("precision must be 'f32' (v_mfma_f32_16x16x4_f32) or 'f16x3' (split-fp16 MFMA)")
-        # the split-fp16 kernel covers the 3x3x3 stride-1 layers with up to 32 output channels (2..32)
-        self.split = precision == "f16x3" and k == 3 and stride == 1 and 1 < self.cout <= 32
+        # the split-fp16 kernel covers the 3x3x3 stride-1 layers (32 output channels per block; wider
+        # layers are split over the grid); the single-channel head stays on its vector-ALU kernel
+        self.split = precision == "f16x3" and k == 3 and stride == 1 and self.cout > 1
         lib = _lib.load()
         with torch.cuda.device(w.device):
             if self.split:

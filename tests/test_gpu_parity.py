@@ -470,3 +470,15 @@ def test_split_fp16_range_guard():
     with pytest.raises(DiffuVolumeError):
         S.check_split_overflow(DEV)
     S.check_split_overflow(DEV)                       # flag was cleared
+
+
+@pytest.mark.parametrize("cfg", [(64, 64, (1, 4, 8, 24)), (128, 128, (1, 4, 4, 12)), (16, 48, (1, 3, 5, 20))])
+def test_conv_f16x3_wide_layers(cfg):
+    """Cout > 32: the grid splits the output channels into 32-wide slices."""
+    cin, cout, dims = cfg
+    g = _gen(19, str(cfg))
+    x = torch.randn(dims[0], cin, *dims[1:], generator=g)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5
+    ref = torch.nn.functional.conv3d(x.double(), w.double(), None, 1, 1)
+    out = S.Conv3dPlan(dev(w), None, 1, S.ACT_NONE, precision="f16x3")(dev(x))
+    assert rel_err(out, ref) < 2e-6

@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--ddim-steps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the split-fp16 and end-to-end side measurements")
     return ap.parse_args()
 
 
@@ -123,6 +124,65 @@ def cpu_baseline(sd, host, ddim_steps):
             "sample": f"oracle/acv_oracle.py, 1 pair 960x512: builders {tb:.2f} s + 1 of {ddim_steps} DDIM steps "
                       f"{ts:.2f} s, extrapolated to {ddim_steps} steps",
             "builders_s": tb, "ddim_step_s": ts}, disp
+
+
+def extras(a, sd, x, mask, device):
+    """Side measurements (not `value`): (1) the same hot path with the 3x3x3 stride-1 convs on the opt-in
+    split-fp16 MFMA kernel; (2) the end-to-end `test_sample` equivalent of SceneFlow/test_sceneflow_ddim.py:
+    89-122 -- origin ACVNet -> used/disp -> ACVNet_DDIM.forward (2-D CNNs in PyTorch/MIOpen) -> metrics."""
+    import diffuvolume_amd as dv
+    from diffuvolume_amd import metrics as M
+    from diffuvolume_amd import submodule as S
+    from diffuvolume_amd.synth import synth_state_dict
+    res = {}
+
+    def timed_loop(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    with torch.no_grad():
+        S.set_default_conv_precision("f16x3")
+        try:
+            m16 = dv.ACVNet_DDIM(192, False, False, sampling_timesteps=a.ddim_steps,
+                                 ensemble_cof=None if a.ddim_steps == 5 else tuple([0.5] + [0.0] * (a.ddim_steps - 1) + [0.5]))
+            m16.load_state_dict(sd, strict=True)
+            m16 = m16.to(device).eval()
+            m16.prepare()
+        finally:
+            S.set_default_conv_precision(None)
+        dt = timed_loop(lambda: M.batch_metrics(hot_path(m16, x)[0], x["gt"], mask), a.steps)
+        res["split_fp16_convs"] = {"value": a.batch / dt, "unit": "pairs/s", "ms_per_step": 1e3 * dt,
+                                   "note": "k3 s1 convs as hi/lo fp16 pairs on v_mfma_f32_16x16x32_f16, fp32 accumulate; "
+                                           "same parity bars as the exact path (tests/test_gpu_parity.py)"}
+        del m16
+        # end to end
+        from diffuvolume_amd.synth import _gen
+        g = _gen(7, "e2e")
+        left = torch.randn(a.batch, 3, a.height, a.width, generator=g).to(device)
+        right = torch.roll(left, -8, dims=-1)
+        origin = dv.ACVNet(192, False, False)
+        origin.load_state_dict(synth_state_dict(origin.state_dict(), seed=3, logit_gain=8.0), strict=True)
+        origin = origin.to(device).eval()
+        ddim = dv.ACVNet_DDIM(192, False, False)
+        ddim.load_state_dict(sd, strict=True)
+        ddim = ddim.to(device).eval()
+
+        def test_sample():
+            used = origin(left, right)[-1]
+            dn = torch.clamp(used, 0, 191).unsqueeze(1)
+            dn = torch.nn.functional.interpolate(dn, size=(a.height // 4, a.width // 4), mode="bilinear") / 4
+            pred = ddim(left, right, used, dn, None)[0]
+            return M.batch_metrics(pred, x["gt"], mask)
+
+        dt = timed_loop(test_sample, 2)
+        res["end_to_end_test_sample"] = {"value": a.batch / dt, "unit": "pairs/s", "ms_per_batch": 1e3 * dt,
+                                         "note": "origin ACVNet + feature CNNs (PyTorch/MIOpen) + attention branch + hot path + metrics"}
+    return res
 
 
 def main():
@@ -213,6 +273,8 @@ def main():
             _, stack, _ = hot_path(model, one, NoiseTape(1))
         d = (stack[1].cpu() - disp_cpu).abs()
         out["parity_vs_oracle_step1"] = {"mean_abs_px": float(d.mean()), "frac_gt_1e-3": float((d > 1e-3).float().mean())}
+    if rank == 0 and world == 1 and not a.no_extras:
+        out["extras"] = extras(a, sd, x, mask, device)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -22,7 +22,8 @@ class DvDdimCoef(Structure):
     """struct dv_ddim_coef (include/diffuvolume_hip.h)."""
     _fields_ = [("sqrt_recip_alpha", c_double), ("sqrt_recipm1_alpha", c_double),
                 ("sqrt_alpha_next", c_double), ("c", c_double), ("sigma", c_double),
-                ("dif_thr", c_float), ("unc_thr", c_float), ("cof", c_float), ("last", c_int)]
+                ("dif_thr", c_float), ("unc_thr", c_float), ("cof", c_float), ("last", c_int),
+                ("clamp_max", c_float), ("ens_dif_thr", c_float)]
 
 
 P = c_void_p
@@ -50,7 +51,7 @@ SIGNATURES = {
     "dv_upsample_softmax_uncertainty_f32": (c_int, [P, P, P, I, I, I, I, I, P]),
     "dv_disparity_regression_f32": (c_int, [P, P, I, I, I, I, P]),
     "dv_encode_two_hot_f32": (c_int, [P, P, I, I, I, P]),
-    "dv_ddim_step": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, POINTER(DvDdimCoef), P]),
+    "dv_ddim_step": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, POINTER(DvDdimCoef), P]),
     "dv_geo_filter_lookup_f32": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "dv_masked_metrics_f32": (c_int, [P, P, P, P, I, I, P]),
 }

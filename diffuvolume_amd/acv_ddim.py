@@ -373,6 +373,7 @@ class ACVNet_DDIM(_HipPlanMixin):
         k.sqrt_recipm1_alpha = float(p.sqrt_recipm1[time])
         k.dif_thr, k.unc_thr, k.cof = self.dif_threshold, self.unc_threshold, cof
         k.last = int(time_next < 0)
+        k.clamp_max, k.ens_dif_thr = float(self.maxdisp - 1), 0.0
         if time_next >= 0:
             alpha, alpha_next = p.alphas_cumprod[time], p.alphas_cumprod[time_next]
             sigma = self.ddim_sampling_eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
@@ -391,7 +392,7 @@ class ACVNet_DDIM(_HipPlanMixin):
         eps32 = eps if (eps is not None and eps.dtype == torch.float32) else None
         eps64 = eps if (eps is not None and eps.dtype == torch.float64) else None
         lib = _lib.load()
-        _lib.check(lib.dv_ddim_step(disp.data_ptr(), unc.data_ptr(), used.data_ptr(),
+        _lib.check(lib.dv_ddim_step(disp.data_ptr(), unc.data_ptr(), used.data_ptr(), 0,
                                     n01.data_ptr() if f32 else 0, 0 if f32 else n01.data_ptr(),
                                     _lib.ptr(eps32), _lib.ptr(eps64), _lib.ptr(fill), mask.data_ptr(),
                                     x_start.data_ptr(), _lib.ptr(pred_noise), _lib.ptr(x_next), _lib.ptr(ens),

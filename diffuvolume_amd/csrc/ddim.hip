@@ -68,7 +68,8 @@ __device__ __forceinline__ float down4(float a, float b, float c, float d) {
 
 // one thread per quarter-resolution pixel; loops over the nbins channels
 __global__ void ddim_step_kernel(const float* __restrict__ disp, const float* __restrict__ unc,
-                                 const float* __restrict__ used, const float* __restrict__ n01f,
+                                 const float* __restrict__ used, const float* __restrict__ coords0,
+                                 const float* __restrict__ n01f,
                                  const double* __restrict__ n01d, const float* __restrict__ epsf,
                                  const double* __restrict__ epsd, const double* __restrict__ fill,
                                  float* __restrict__ mask, float* __restrict__ x_start,
@@ -82,13 +83,15 @@ __global__ void ddim_step_kernel(const float* __restrict__ disp, const float* __
   const int W = 4 * w;
   const size_t full = b * (size_t)(16 * h) * w;  // b * H * W
   const size_t r0 = full + (size_t)(4 * y + 1) * W + 4 * x + 1, r1 = r0 + W;
-  const float maxd = (float)(4 * nbins - 1);
+  const float maxd = k.clamp_max;
   auto cl = [&](float v) { return fminf(fmaxf(v, 0.f), maxd); };
   // quarter-resolution disparity of this step's prediction (acv_ddim.py:272-274)
-  const float dq = down4(cl(disp[r0]), cl(disp[r0 + 1]), cl(disp[r1]), cl(disp[r1 + 1])) / 4.0f;
-  // renewal mask (acv_ddim.py:322-338)
+  float dq = down4(cl(disp[r0]), cl(disp[r0 + 1]), cl(disp[r1]), cl(disp[r1 + 1])) / 4.0f;
+  if (coords0)   // IGEV: true_coords1 = clamp(coords0 + disp_net, 0, nbins-1) (igev_stereo_ddim.py:270-272)
+    dq = fminf(fmaxf(coords0[i] + dq, 0.f), (float)(nbins - 1));
+  // renewal mask (acv_ddim.py:322-338); unc == nullptr: disparity test only (IGEV, :316-317)
   auto keep = [&](size_t p) {
-    return (fabsf(disp[p] - used[p]) < k.dif_thr && unc[p] < k.unc_thr) ? 1.f : 0.f;
+    return (fabsf(disp[p] - used[p]) < k.dif_thr && (!unc || unc[p] < k.unc_thr)) ? 1.f : 0.f;
   };
   float mk = mask[i] + down4(keep(r0), keep(r0 + 1), keep(r1), keep(r1 + 1));
   mk = fminf(fmaxf(mk, 0.f), 1.f);
@@ -113,10 +116,15 @@ __global__ void ddim_step_kernel(const float* __restrict__ disp, const float* __
   }
 }
 
-__global__ void ensemble_accumulate_kernel(const float* __restrict__ disp, float* __restrict__ ens,
-                                           float cof, size_t total) {
+// ens += cof * disp; with ens_dif_thr > 0 the IGEV output rule applies first:
+// disp' = |disp - used| < thr ? disp : used (igev_stereo_ddim.py:323-327)
+__global__ void ensemble_accumulate_kernel(const float* __restrict__ disp, const float* __restrict__ used,
+                                           float* __restrict__ ens, float cof, float thr, size_t total) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < total) ens[i] += disp[i] * cof;
+  if (i >= total) return;
+  float d = disp[i];
+  if (thr > 0.f && !(fabsf(d - used[i]) < thr)) d = used[i];
+  ens[i] += d * cof;
 }
 
 inline unsigned nblk(size_t total, int threads = 256) { return (unsigned)((total + threads - 1) / threads); }
@@ -159,12 +167,12 @@ extern "C" int dv_encode_two_hot_f32(const float* disp_q, float* x, int B, int n
   return dv_launch_status();
 }
 
-extern "C" int dv_ddim_step(const float* disp, const float* unc, const float* used, const float* n01_f32,
+extern "C" int dv_ddim_step(const float* disp, const float* unc, const float* used, const float* coords0,
+                            const float* n01_f32,
                             const double* n01_f64, const float* eps_f32, const double* eps_f64,
                             const double* fill, float* mask, float* x_start, double* pred_eps,
                             double* x_next, float* ens, int B, int nbins, int h, int w, const dv_ddim_coef* coef, dv_stream_t stream) {
   DV_REQUIRE_PTR(disp);
-  DV_REQUIRE_PTR(unc);
   DV_REQUIRE_PTR(used);
   DV_REQUIRE_PTR(mask);
   DV_REQUIRE_PTR(x_start);
@@ -178,14 +186,14 @@ extern "C" int dv_ddim_step(const float* disp, const float* unc, const float* us
   }
   hipStream_t s = (hipStream_t)stream;
   const size_t total = (size_t)B * h * w;
-  hipLaunchKernelGGL(ddim_step_kernel, dim3(nblk(total, 128)), dim3(128), 0, s, disp, unc, used, n01_f32,
+  hipLaunchKernelGGL(ddim_step_kernel, dim3(nblk(total, 128)), dim3(128), 0, s, disp, unc, used, coords0, n01_f32,
                      n01_f64, eps_f32, eps_f64, fill, mask, x_start, pred_eps, x_next, nbins, h, w, total, *coef);
   int rc = dv_launch_status();
   if (rc != DV_OK) return rc;
   if (ens != nullptr && coef->cof != 0.f) {
     const size_t full = total * 16;
-    hipLaunchKernelGGL(ensemble_accumulate_kernel, dim3(nblk(full)), dim3(256), 0, s, disp, ens, coef->cof,
-                       full);
+    hipLaunchKernelGGL(ensemble_accumulate_kernel, dim3(nblk(full)), dim3(256), 0, s, disp, used, ens, coef->cof,
+                       coef->ens_dif_thr, full);
     rc = dv_launch_status();
   }
   return rc;

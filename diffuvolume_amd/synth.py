@@ -116,3 +116,19 @@ class NoiseTape:
         g = _gen(self.seed, f"{kind}{k}")
         fn = torch.rand if kind == "fill" else torch.randn
         return fn(tuple(shape), generator=g, dtype=torch.float64).to(dtype)
+
+
+def toy_update_block(net_list, inp_list, corr=None, flow=None, iter32=True, iter16=True, iter08=True, update=True):
+    """Deterministic stand-in for IGEV's ConvGRU update block (KITTI15/core/update.py:104-142, a 2-D module that
+    is out of scope): same call signature and return convention, so the reference's and this build's DDIM
+    loops can be driven with identical dynamics in the parity fixtures."""
+    if not update:
+        return net_list
+    delta = 0.3 * torch.tanh(corr.mean(dim=1, keepdim=True)) - 0.02 * flow
+    return net_list, torch.ones_like(flow), delta
+
+
+def toy_upsample_disp(flow, up_mask, stem_2x):
+    """Stand-in for IGEVStereo_ddim.upsample_disp (:206-214): x4 bilinear upsampling of 4*flow."""
+    import torch.nn.functional as F
+    return F.interpolate(flow * 4.0, scale_factor=4, mode="bilinear", align_corners=False)

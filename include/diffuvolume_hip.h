@@ -160,9 +160,13 @@ typedef struct dv_ddim_coef {
   float unc_thr;             /* 3  (acv_ddim.py:330) */
   float cof;                 /* ensemble weight of this step's disparity (acv_ddim.py:367) */
   int last;                  /* time_next < 0 (acv_ddim.py:344-346) */
+  float clamp_max;           /* clamp of disp before the /4 downsample: 4*nbins-1 (ACV/PCW), nbins-1 (IGEV :265) */
+  float ens_dif_thr;         /* >0: ensemble takes |disp-used|<thr ? disp : used (IGEV :323-327); 0: disp */
 } dv_ddim_coef;
 
-int dv_ddim_step(const float* disp, const float* unc, const float* used,
+/* unc may be NULL (IGEV renewal mask tests the disparity only); coords0 [B,h,w] is NULL except for IGEV,
+ * where the two-hot position is clamp(coords0 + disp_q, 0, nbins-1) (igev_stereo_ddim.py:268-272). */
+int dv_ddim_step(const float* disp, const float* unc, const float* used, const float* coords0,
                  const float* n01_f32, const double* n01_f64,
                  const float* eps_f32, const double* eps_f64, const double* fill,
                  float* mask, float* x_start, double* pred_eps, double* x_next, float* ens,

@@ -51,3 +51,82 @@ def geo_filter_lookup(geo_volume, init_fmap1, init_fmap2, disp, coords, noisy, r
         noi = F.avg_pool1d(noi, 2, 2)
     out = torch.cat(outs, dim=-1).view(b, h, w, -1)
     return out.permute(0, 3, 1, 2).contiguous().float()
+
+
+# ---------------------------------------------------------------------------------------------------
+# DDIM loop of IGEVStereo_ddim (KITTI15/core/igev_stereo_ddim.py:226-359), pinned by tests/golden/igev_loop.npz
+# (vectors produced by the reference's own two methods bound to a light object, oracle/make_golden_igev_loop.py)
+# ---------------------------------------------------------------------------------------------------
+def head180_shift(t, sd, bins: int = 48):
+    """core/head.py:22-34,:74-77: sinusoidal(180) MLP, then linear interpolation of the 180-vector to `bins`."""
+    import math
+    half = 90
+    freq = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1)))
+    emb = t[:, None] * freq[None, :]
+    emb = torch.cat((emb.sin(), emb.cos()), dim=-1)
+    y = F.linear(emb, sd["time_mlp.1.weight"], sd["time_mlp.1.bias"])
+    y = F.linear(F.gelu(y), sd["time_mlp.3.weight"], sd["time_mlp.3.bias"])
+    y = F.linear(F.silu(y), sd["block_time_mlp.1.weight"], sd["block_time_mlp.1.bias"])
+    return F.interpolate(y.unsqueeze(1), bins, mode="linear").squeeze(1)
+
+
+class IGEVLoopOracle:
+    def __init__(self, head_sd, update_block, upsample_disp, geo, f1, f2, sampling_timesteps=2, cof=(0.6, 0.1, 0.3)):
+        from . import acv_oracle as A
+        self.A, self.head_sd, self.update_block, self.upsample_disp = A, head_sd, update_block, upsample_disp
+        self.geo, self.f1, self.f2 = geo, f1, f2
+        self.S, self.cof = sampling_timesteps, cof
+        ac = A.cosine_alphas_cumprod(1000)
+        self.ac, self.sqrt_ac, self.sqrt_1m = ac, torch.sqrt(ac), torch.sqrt(1 - ac)
+        self.sr, self.srm1 = torch.sqrt(1 / ac), torch.sqrt(1 / ac - 1)
+
+    def corr_fn(self, disp, coords, noisy):
+        return geo_filter_lookup(self.geo, self.f1, self.f2, disp, coords, noisy)
+
+    def model_predictions(self, coords0, coords1, iters, x_t, t):
+        """:226-292 (n_gru_layers=3, slow_fast_gru=False, flow_init=None)."""
+        A = self.A
+        n01 = ((torch.clamp(x_t + head180_shift(t, self.head_sd)[:, :, None, None], -1, 1)) + 1) / 2
+        nets = [None]
+        for itr in range(iters):
+            flow = coords1 - coords0
+            corr = self.corr_fn(flow, coords1, n01.float())
+            nets, up_mask, delta = self.update_block(nets, [None], corr, flow, iter16=True, iter08=True)
+            coords1 = coords1 + delta
+        pred = self.upsample_disp(coords1 - coords0, up_mask, None)[:, :1]
+        b, _, hh, ww = pred.shape
+        dn = F.interpolate(torch.clamp(pred, 0, 47), size=(hh // 4, ww // 4), mode="bilinear") / 4
+        tc = torch.clamp(coords0 + dn, 0, 47)
+        x_start = torch.clamp(A.encode_two_hot(tc, 48) * 2 - 1.0, -1, 1)
+        bs = (b, 1, 1, 1)
+        pn = (self.sr.gather(-1, t).reshape(bs) * n01 - x_start) / self.srm1.gather(-1, t).reshape(bs)
+        return pn, x_start, pred, coords1
+
+    def ddim_sample(self, coords0, coords1, iters, used, asd, draw):
+        """:294-359."""
+        b, d, h, w = asd.shape
+        img = draw("x_T", tuple(asd.shape), asd.dtype)
+        final = [used]
+        mask = torch.zeros(b, h, w)
+        times = list(reversed(torch.linspace(-1, 999, steps=self.S + 1).int().tolist()))
+        for time, time_next in zip(times[:-1], times[1:]):
+            t = torch.full((b,), time, dtype=torch.long)
+            pn, x_start, disp, coords1 = self.model_predictions(coords0, coords1, iters, img, t)
+            dif = torch.abs(disp - used)
+            keep = F.interpolate((dif < 5).float(), size=(h, w), mode="bilinear").squeeze(1)
+            mask = torch.clamp(mask + keep, 0, 1)
+            final.append(torch.where(dif < 3, disp, used))
+            if time_next < 0:
+                img = x_start
+                continue
+            a, an = self.ac[time], self.ac[time_next]
+            sigma = ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
+            c = (1 - an - sigma ** 2).sqrt()
+            eps = draw("eps", tuple(img.shape), img.dtype)
+            img = x_start * an.sqrt() + c * pn + sigma * eps
+            tt = torch.full((1,), time, dtype=torch.long)
+            fill = (self.sqrt_ac.gather(-1, tt).reshape(1, 1, 1, 1) * asd
+                    + self.sqrt_1m.gather(-1, tt).reshape(1, 1, 1, 1) * draw("q", tuple(asd.shape), asd.dtype))
+            img = torch.where(mask.unsqueeze(1) == 0, fill, img)
+        stack = torch.cat(final, dim=1)                                  # [B, S+1, H, W]
+        return (stack * torch.tensor(self.cof).view(1, -1, 1, 1)).sum(dim=1)

@@ -16,20 +16,31 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kTD = 2, kTH = 2, kMTX = 2, kNT = 2, kKC = 8;
+constexpr int kTD = 2, kTH = 2, kMTX = 2, kNT = 2;
 constexpr int kTW = kMTX * 16;
-constexpr int kIZ = kTD + 1, kIY = kTH + 1, kIX = kTW + 1;
-constexpr int kPRAW = kIZ * kIY * kIX;                      // 297
-constexpr int kP = kPRAW + ((16 - kPRAW % 32) + 32) % 32;   // == 16 (mod 32): 304
 constexpr int kCOUT = kNT * 16;
-constexpr int kT = 27;
-constexpr int kInFloats = kKC * kP;
-constexpr int kWFloats = kT * kKC * kCOUT;
-static_assert(kP % 32 == 16, "bank rule");
+
+// K = 3: ConvTranspose3d(3, stride 2, padding 1, output_padding 1)   (ACV / PCW hourglass)
+// K = 4: ConvTranspose3d(4, stride 2, padding 1)                      (IGEV hourglass, igev_stereo_ddim.py:44-51)
+// Both double every dimension.  Per dimension o = 2i - 1 + k:  parity(k) = (k+1)&1, input offset (k==0) - (k==3).
+template <int K, int KC_>
+struct DGeo {
+  static constexpr int KC = KC_;
+  static constexpr int LO = (K == 4) ? 1 : 0;                 // halo below (k == 3 reads i-1)
+  static constexpr int T = K * K * K;
+  static constexpr int IZ = kTD + 1 + LO, IY = kTH + 1 + LO, IX = kTW + 1 + LO;
+  static constexpr int PRAW = IZ * IY * IX;
+  static constexpr int P = PRAW + ((16 - PRAW % 32) + 32) % 32;   // == 16 (mod 32)
+  static constexpr int IN_FLOATS = KC * P, W_FLOATS = T * KC * kCOUT;
+  static_assert(P % 32 == 16, "bank rule");
+  static_assert((IN_FLOATS + W_FLOATS) * 4 <= 80 * 1024, "two blocks per CU");
+};
+__host__ __device__ constexpr int tap_par(int k) { return (k + 1) & 1; }
+__host__ __device__ constexpr int tap_off(int k) { return (k == 0 ? 1 : 0) - (k == 3 ? 1 : 0); }
 
 struct DeconvArgs {
   const float* in;
-  const float* wpk;  // [Cinp/2][27][Coutp][2]
+  const float* wpk;  // [Cinp/2][K^3][Coutp][2]
   const float* ch_scale;
   const float* ch_bias;
   const float* residual;  // [B,Cout,2D,2H,2W] or null
@@ -40,10 +51,13 @@ struct DeconvArgs {
   int vec_store;
 };
 
+template <int K, int KC_>
 __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[kInFloats + kWFloats];
+  using G = DGeo<K, KC_>;
+  constexpr int kKC = G::KC, kT = G::T, kIY = G::IY, kIX = G::IX, kPRAW = G::PRAW, kP = G::P, LO = G::LO;
+  __shared__ __attribute__((aligned(16))) float smem[G::IN_FLOATS + G::W_FLOATS];
   float* in_s = smem;
-  float* w_s = smem + kInFloats;
+  float* w_s = smem + G::IN_FLOATS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kq = lane >> 4;
 
@@ -64,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
 #pragma unroll
       for (int n = 0; n < kNT; ++n) acc[m][c][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int abase = kq * kP + (zl * kIY + yl) * kIX + j;
+  const int abase = kq * kP + ((zl + LO) * kIY + yl + LO) * kIX + j + LO;
   const int bbase = ((kq >> 1) * kT * kCOUT + j) * 2 + (kq & 1);
   const size_t plane = (size_t)a.H * a.W, vol = (size_t)a.D * plane;
   const float* inb = a.in + (size_t)b * a.Cin * vol;
@@ -81,8 +95,9 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
     const int r = tid + 256 * i;
     const int zz = r / (kIY * kIX), r2 = r - zz * (kIY * kIX);
     const int yy = r2 / kIX, xx = r2 - yy * kIX;
-    const int z = z0 + zz, y = y0 + yy, x = x0 + xx;
-    sp[i] = (r < kPRAW && z < a.D && y < a.H && x < a.W) ? (z * a.H + y) * a.W + x : -1;
+    const int z = z0 - LO + zz, y = y0 - LO + yy, x = x0 - LO + xx;
+    sp[i] = (r < kPRAW && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
+                ? (z * a.H + y) * a.W + x : -1;
   }
   float vin[kKC][NS];
   f32x4 vw[NWQ];
@@ -124,13 +139,13 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
     __syncthreads();
     if (c0 + kKC < a.Cin) fetch(c0 + kKC);
 #pragma unroll
-    for (int kzy = 0; kzy < 9; ++kzy) {
-      const int kz = kzy / 3, ky = kzy - kz * 3;
-      const float* arow = in_s + abase + ((kz == 0) * kIY + (ky == 0)) * kIX;
-      const float* brow = w_s + bbase + kzy * 3 * kCOUT * 2;
+    for (int kzy = 0; kzy < K * K; ++kzy) {
+      const int kz = kzy / K, ky = kzy - kz * K;
+      const float* arow = in_s + abase + (tap_off(kz) * kIY + tap_off(ky)) * kIX;
+      const float* brow = w_s + bbase + kzy * K * kCOUT * 2;
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int cls = ((kz != 1) << 2) | ((ky != 1) << 1) | (kx != 1);
+      for (int kx = 0; kx < K; ++kx) {
+        const int cls = (tap_par(kz) << 2) | (tap_par(ky) << 1) | tap_par(kx);
 #pragma unroll
         for (int ks = 0; ks < kKC / 4; ++ks) {
           float bf[kNT];
@@ -138,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
           for (int n = 0; n < kNT; ++n) bf[n] = brow[((ks * 2 * kT + kx) * kCOUT + n * 16) * 2];
 #pragma unroll
           for (int m = 0; m < kMTX; ++m) {
-            const float av = arow[m * 16 + ks * 4 * kP + (kx == 0)];
+            const float av = arow[m * 16 + ks * 4 * kP + tap_off(kx)];
 #pragma unroll
             for (int n = 0; n < kNT; ++n)
               acc[m][cls][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bf[n], acc[m][cls][n], 0, 0, 0);
@@ -199,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
 }
 
 __global__ void pack_deconv_weights_kernel(const float* __restrict__ w, float* __restrict__ wpk, int Cin,
-                                           int Cout, int Cinp, int Coutp) {
+                                           int Cout, int Cinp, int Coutp, int kT) {
   const size_t total = (size_t)Cinp * kT * Coutp;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
@@ -214,35 +229,25 @@ __global__ void pack_deconv_weights_kernel(const float* __restrict__ w, float* _
 
 inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 
-}  // namespace
-
-extern "C" size_t dv_deconv3d_packed_floats(int Cin, int Cout) {
-  if (Cin <= 0 || Cout <= 0) return 0;
-  return (size_t)pad_to(Cin, 8) * kT * pad_to(Cout, kCOUT);
-}
-
-extern "C" int dv_deconv3d_pack_weights_f32(const float* w, float* wpacked, int Cin, int Cout,
-                                            dv_stream_t stream) {
-  DV_REQUIRE_PTR(w);
-  DV_REQUIRE_PTR(wpacked);
-  DV_REQUIRE(Cin > 0 && Cout > 0, DV_ERR_SHAPE);
-  const int Cinp = pad_to(Cin, 8), Coutp = pad_to(Cout, kCOUT);
-  const size_t total = (size_t)Cinp * kT * Coutp;
-  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(pack_deconv_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
-                     wpacked, Cin, Cout, Cinp, Coutp);
+template <int K, int KC_>
+int launch_deconv(DeconvArgs a, hipStream_t s) {
+  const long long blocks = (long long)a.B * a.nco * a.ntz * a.nty * a.ntx;
+  if (blocks <= 0 || blocks > 0x7fffffffLL) return DV_ERR_SHAPE;
+  hipLaunchKernelGGL((deconv3d_mfma_kernel<K, KC_>), dim3((unsigned)blocks), dim3(256), 0, s, a);
   return dv_launch_status();
 }
 
-extern "C" int dv_deconv3d_k3s2_f32(const float* in, const float* wpacked, const float* ch_scale,
-                                    const float* ch_bias, const float* residual, float* out, int B,
-                                    int Cin, int D, int H, int W, int Cout, int act, dv_stream_t stream) {
-  DV_REQUIRE_PTR(in);
-  DV_REQUIRE_PTR(wpacked);
-  DV_REQUIRE_PTR(out);
-  DV_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0 && Cout > 0, DV_ERR_SHAPE);
-  DV_REQUIRE(act >= DV_ACT_NONE && act <= DV_ACT_LEAKY, DV_ERR_UNSUPPORTED);
-  DV_REQUIRE(dv_aligned16(wpacked), DV_ERR_ALIGN);
+int pack_any(const float* w, float* wpacked, int Cin, int Cout, int K, hipStream_t s) {
+  const int T = K * K * K, Cinp = pad_to(Cin, 8), Coutp = pad_to(Cout, kCOUT);
+  const size_t total = (size_t)Cinp * T * Coutp;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_deconv_weights_kernel, dim3(blocks), dim3(256), 0, s, w, wpacked, Cin, Cout, Cinp, Coutp, T);
+  return dv_launch_status();
+}
+
+int run_any(const float* in, const float* wpacked, const float* ch_scale, const float* ch_bias,
+            const float* residual, float* out, int B, int Cin, int D, int H, int W, int Cout, int act, int K,
+            hipStream_t s) {
   DeconvArgs a;
   a.in = in; a.wpk = wpacked; a.ch_scale = ch_scale; a.ch_bias = ch_bias; a.residual = residual;
   a.out = out; a.B = B; a.Cin = Cin; a.D = D; a.H = H; a.W = W; a.Cout = Cout;
@@ -253,8 +258,53 @@ extern "C" int dv_deconv3d_k3s2_f32(const float* in, const float* wpacked, const
   a.nco = a.Coutp / kCOUT;
   a.act = act;
   a.vec_store = (W % 4 == 0) && dv_aligned16(out) && (!residual || dv_aligned16(residual));
-  const long long blocks = (long long)B * a.nco * a.ntz * a.nty * a.ntx;
-  if (blocks <= 0 || blocks > 0x7fffffffLL) return DV_ERR_SHAPE;
-  hipLaunchKernelGGL(deconv3d_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
-  return dv_launch_status();
+  return K == 3 ? launch_deconv<3, 8>(a, s) : launch_deconv<4, 4>(a, s);
+}
+
+}  // namespace
+
+extern "C" size_t dv_deconv3d_packed_floats(int Cin, int Cout) {
+  if (Cin <= 0 || Cout <= 0) return 0;
+  return (size_t)pad_to(Cin, 8) * 27 * pad_to(Cout, kCOUT);
+}
+
+extern "C" size_t dv_deconv3d_k4_packed_floats(int Cin, int Cout) {
+  if (Cin <= 0 || Cout <= 0) return 0;
+  return (size_t)pad_to(Cin, 8) * 64 * pad_to(Cout, kCOUT);
+}
+
+extern "C" int dv_deconv3d_pack_weights_f32(const float* w, float* wpacked, int Cin, int Cout, dv_stream_t stream) {
+  DV_REQUIRE_PTR(w);
+  DV_REQUIRE_PTR(wpacked);
+  DV_REQUIRE(Cin > 0 && Cout > 0, DV_ERR_SHAPE);
+  return pack_any(w, wpacked, Cin, Cout, 3, (hipStream_t)stream);
+}
+
+extern "C" int dv_deconv3d_k4_pack_weights_f32(const float* w, float* wpacked, int Cin, int Cout, dv_stream_t stream) {
+  DV_REQUIRE_PTR(w);
+  DV_REQUIRE_PTR(wpacked);
+  DV_REQUIRE(Cin > 0 && Cout > 0, DV_ERR_SHAPE);
+  return pack_any(w, wpacked, Cin, Cout, 4, (hipStream_t)stream);
+}
+
+#define DV_DECONV_CHECKS                                                             \
+  DV_REQUIRE_PTR(in);                                                                \
+  DV_REQUIRE_PTR(wpacked);                                                           \
+  DV_REQUIRE_PTR(out);                                                               \
+  DV_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0 && Cout > 0, DV_ERR_SHAPE);  \
+  DV_REQUIRE(act >= DV_ACT_NONE && act <= DV_ACT_LEAKY, DV_ERR_UNSUPPORTED);         \
+  DV_REQUIRE(dv_aligned16(wpacked), DV_ERR_ALIGN);
+
+extern "C" int dv_deconv3d_k3s2_f32(const float* in, const float* wpacked, const float* ch_scale,
+                                    const float* ch_bias, const float* residual, float* out, int B,
+                                    int Cin, int D, int H, int W, int Cout, int act, dv_stream_t stream) {
+  DV_DECONV_CHECKS
+  return run_any(in, wpacked, ch_scale, ch_bias, residual, out, B, Cin, D, H, W, Cout, act, 3, (hipStream_t)stream);
+}
+
+extern "C" int dv_deconv3d_k4s2_f32(const float* in, const float* wpacked, const float* ch_scale,
+                                    const float* ch_bias, const float* residual, float* out, int B,
+                                    int Cin, int D, int H, int W, int Cout, int act, dv_stream_t stream) {
+  DV_DECONV_CHECKS
+  return run_any(in, wpacked, ch_scale, ch_bias, residual, out, B, Cin, D, H, W, Cout, act, 4, (hipStream_t)stream);
 }

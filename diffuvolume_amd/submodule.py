@@ -258,23 +258,26 @@ class Conv3dPlan:
 
 
 class Deconv3dPlan:
-    """ConvTranspose3d(k=3, s=2, p=1, output_padding=1, bias=False) + BatchNorm3d (eval)
-    + skip add + activation (acv_ddim.py:74-80, :91-92)."""
+    """ConvTranspose3d(stride 2, padding 1, bias=False) + BatchNorm3d (eval) + skip add + activation that
+    doubles every dimension: kernel 3 with output_padding 1 (acv_ddim.py:74-80, :91-92) or kernel 4
+    (IGEV hourglass, igev_stereo_ddim.py:44-51)."""
 
     def __init__(self, weight: torch.Tensor, bn: Optional[Tuple[torch.Tensor, ...]] = None,
                  act: int = ACT_NONE, eps: float = 1e-5):
         w = _dev_f32(weight.detach(), "weight")
-        self.cin, self.cout = w.shape[0], w.shape[1]
-        if tuple(w.shape[2:]) != (3, 3, 3):
-            raise _lib.DiffuVolumeError("only the k3 s2 p1 op1 transposed convolution is implemented")
-        self.act = act
+        self.cin, self.cout, k = w.shape[0], w.shape[1], w.shape[2]
+        if tuple(w.shape[2:]) != (k, k, k) or k not in (3, 4):
+            raise _lib.DiffuVolumeError("transposed convolutions: k3 s2 p1 op1 and k4 s2 p1 are implemented")
+        self.k, self.act = k, act
         lib = _lib.load()
-        n = lib.dv_deconv3d_packed_floats(self.cin, self.cout)
-        self.wpacked = torch.empty(n, dtype=torch.float32, device=w.device)
+        sizer, packer, self._run, self._name = (
+            (lib.dv_deconv3d_packed_floats, lib.dv_deconv3d_pack_weights_f32, lib.dv_deconv3d_k3s2_f32, "dv_deconv3d_k3s2_f32")
+            if k == 3 else
+            (lib.dv_deconv3d_k4_packed_floats, lib.dv_deconv3d_k4_pack_weights_f32, lib.dv_deconv3d_k4s2_f32, "dv_deconv3d_k4s2_f32"))
+        self.wpacked = torch.empty(sizer(self.cin, self.cout), dtype=torch.float32, device=w.device)
         with torch.cuda.device(w.device):
-            _lib.check(lib.dv_deconv3d_pack_weights_f32(w.data_ptr(), self.wpacked.data_ptr(), self.cin,
-                                                        self.cout, _lib.stream_ptr()),
-                       "dv_deconv3d_pack_weights_f32")
+            _lib.check(packer(w.data_ptr(), self.wpacked.data_ptr(), self.cin, self.cout, _lib.stream_ptr()),
+                       "deconv weight packing")
         self.scale, self.shift = _fold_bn(bn, None, self.cout, w.device, eps)
 
     def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -287,15 +290,12 @@ class Deconv3dPlan:
             residual = _dev_f32(residual, "residual")
             if tuple(residual.shape) != tuple(out.shape):
                 raise RuntimeError("residual shape mismatch")
-        lib = _lib.load()
         with torch.cuda.device(x.device):
             nb = 4.0 * (x.numel() + out.numel() * (1 if residual is None else 2))
-            timed("deconv3d_k3s2", 2.0 * x.numel() * self.cout * 27, nb,
-                  lambda: _lib.check(lib.dv_deconv3d_k3s2_f32(x.data_ptr(), self.wpacked.data_ptr(),
-                                                              _lib.ptr(self.scale), _lib.ptr(self.shift),
-                                                              _lib.ptr(residual), out.data_ptr(), b, cin, d, h, w,
-                                                              self.cout, self.act, _lib.stream_ptr()),
-                                     "dv_deconv3d_k3s2_f32"))
+            timed(f"deconv3d_k{self.k}s2", 2.0 * x.numel() * self.cout * self.k ** 3, nb,
+                  lambda: _lib.check(self._run(x.data_ptr(), self.wpacked.data_ptr(), _lib.ptr(self.scale),
+                                               _lib.ptr(self.shift), _lib.ptr(residual), out.data_ptr(), b, cin, d, h,
+                                               w, self.cout, self.act, _lib.stream_ptr()), self._name))
         return out
 
 

@@ -106,6 +106,16 @@ int dv_deconv3d_k3s2_f32(const float* in, const float* wpacked, const float* ch_
                          const float* ch_bias, const float* residual, float* out,
                          int B, int Cin, int D, int H, int W, int Cout, int act, dv_stream_t stream);
 
+/* nn.ConvTranspose3d(kernel 4, stride 2, padding 1, bias=False) [+BN +LeakyReLU]: the IGEV hourglass's
+ * conv3_up / conv2_up / conv1_up (KITTI15/core/igev_stereo_ddim.py:44-51, BasicConv deconv core/submodule.py:9-35).
+ * w [Cin,Cout,4,4,4]; in [B,Cin,D,H,W] -> out [B,Cout,2D,2H,2W]; same fused epilogue as the k3 flavour. */
+size_t dv_deconv3d_k4_packed_floats(int Cin, int Cout);
+int dv_deconv3d_k4_pack_weights_f32(const float* w /*[Cin,Cout,4,4,4]*/, float* wpacked,
+                                    int Cin, int Cout, dv_stream_t stream);
+int dv_deconv3d_k4s2_f32(const float* in, const float* wpacked, const float* ch_scale,
+                         const float* ch_bias, const float* residual, float* out,
+                         int B, int Cin, int D, int H, int W, int Cout, int act, dv_stream_t stream);
+
 /* attention_block.forward: SceneFlow/models/submodule.py:398-429 -- 4x4x4 window
  * multi-head self-attention (heads x C/heads), qkv Linear(C,3C)+bias, softmax,
  * final 1x1x1 Conv3d(C,C)+bias.  x [B,C,D,H,W] -> out same shape.  D must be a

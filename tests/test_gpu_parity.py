@@ -482,3 +482,19 @@ def test_conv_f16x3_wide_layers(cfg):
     ref = torch.nn.functional.conv3d(x.double(), w.double(), None, 1, 1)
     out = S.Conv3dPlan(dev(w), None, 1, S.ACT_NONE, precision="f16x3")(dev(x))
     assert rel_err(out, ref) < 2e-6
+
+
+@pytest.mark.parametrize("cfg", [(48, 32, (1, 3, 4, 10)), (32, 16, (2, 2, 5, 13)), (16, 8, (1, 4, 6, 32))])
+def test_deconv_k4_oracle(cfg):
+    """ConvTranspose3d(4, stride 2, padding 1) + BN + LeakyReLU (IGEV hourglass, igev_stereo_ddim.py:44-51)."""
+    cin, cout, dims = cfg
+    g = _gen(21, str(cfg))
+    x = torch.randn(dims[0], cin, *dims[1:], generator=g)
+    w = torch.randn(cin, cout, 4, 4, 4, generator=g) * (2.0 / (64 * cin)) ** 0.5
+    bn = (torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1,
+          torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5)
+    up = torch.nn.functional.conv_transpose3d(x, w, None, 2, 1)
+    y = torch.nn.functional.leaky_relu(torch.nn.functional.batch_norm(up, bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5), 0.01)
+    plan = S.Deconv3dPlan(dev(w), tuple(dev(t) for t in bn), act=S.ACT_LEAKY)
+    out = plan(dev(x))
+    assert out.shape == y.shape and rel_err(out, y) < 1e-5

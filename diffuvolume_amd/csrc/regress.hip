@@ -164,7 +164,35 @@ __global__ void disparity_regression_kernel(const float* __restrict__ prob, floa
   disp[i] = acc;
 }
 
+// F.softmax(cost, dim=1) + disparity_regression with no upsampling (IGEV init_disp,
+// igev_stereo_ddim.py:382-383): one thread per pixel, three passes over its D logits (L2-resident).
+__global__ void softmax_regress_kernel(const float* __restrict__ cost, float* __restrict__ disp, int D,
+                                       size_t plane, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const size_t b = i / plane, p = i - b * plane;
+  const float* src = cost + b * D * plane + p;
+  float mx = src[0];
+  for (int d = 1; d < D; ++d) mx = fmaxf(mx, src[(size_t)d * plane]);
+  float sum = 0.f;
+  for (int d = 0; d < D; ++d) sum += expf(src[(size_t)d * plane] - mx);
+  float acc = 0.f;
+  for (int d = 0; d < D; ++d) acc += (expf(src[(size_t)d * plane] - mx) / sum) * (float)d;
+  disp[i] = acc;
+}
+
 }  // namespace
+
+extern "C" int dv_softmax_regress_f32(const float* cost, float* disp, int B, int D, int H, int W,
+                                      dv_stream_t stream) {
+  DV_REQUIRE_PTR(cost);
+  DV_REQUIRE_PTR(disp);
+  DV_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, DV_ERR_SHAPE);
+  const size_t plane = (size_t)H * W, total = plane * B;
+  hipLaunchKernelGGL(softmax_regress_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, cost, disp, D, plane, total);
+  return dv_launch_status();
+}
 
 static int launch_tail(const float* cost, const float* disp_in, float* disp, float* unc, int B, int D, int h,
                        int w, int align_corners, hipStream_t s) {

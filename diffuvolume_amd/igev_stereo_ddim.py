@@ -23,7 +23,8 @@ from torch import nn
 from . import _lib
 from .acv_ddim import cosine_beta_schedule
 from .head import SinusoidalPositionEmbeddings
-from .submodule import _dev_f32
+from .submodule import (ACT_LEAKY, ACT_NONE, Conv3dPlan, Deconv3dPlan, _dev_f32, build_gwc_volume,
+                        feature_gate, softmax_regress)
 
 
 class DynamicHead180(nn.Module):
@@ -180,3 +181,157 @@ class IGEVDiffusionLoop:
             x_start, x_next, _ = self._update(pred2, used2, c0, n01, eps, fill, mask, ens, coef)
             img = x_start if time_next < 0 else x_next
         return ens
+
+
+# ---------------------------------------------------------------------------------------------------
+# The once-per-pair cost-volume front of IGEVStereo_ddim.forward (igev_stereo_ddim.py:377-386):
+# gwc volume (8 groups) -> corr_stem -> FeatureAtt -> hourglass(8) -> classifier -> softmax -> regression.
+# Module and parameter names are the reference's, so its checkpoints load unchanged
+# (`corr_stem.conv.weight`, `cost_agg.feature_att_16.feat_att.1.bias`, ...).
+# ---------------------------------------------------------------------------------------------------
+class BasicConv(nn.Module):
+    """core/submodule.py:9-35: conv (bias=False) [+ BatchNorm] [+ LeakyReLU(0.01)].  The 3-D flavours run as
+    fused HIP plans (``plan()``); ``forward`` is the 2-D flavour used inside FeatureAtt."""
+
+    def __init__(self, in_channels, out_channels, deconv=False, is_3d=False, bn=True, relu=True, **kwargs):
+        super().__init__()
+        self.relu, self.use_bn, self.is_3d, self.deconv = relu, bn, is_3d, deconv
+        if is_3d:
+            self.conv = (nn.ConvTranspose3d if deconv else nn.Conv3d)(in_channels, out_channels, bias=False, **kwargs)
+            self.bn = nn.BatchNorm3d(out_channels)
+        else:
+            self.conv = (nn.ConvTranspose2d if deconv else nn.Conv2d)(in_channels, out_channels, bias=False, **kwargs)
+            self.bn = nn.BatchNorm2d(out_channels)
+
+    def plan(self):
+        if not self.is_3d:
+            raise _lib.DiffuVolumeError("only the 3-D BasicConv flavours have HIP plans")
+        bn = (self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var) if self.use_bn else None
+        act = ACT_LEAKY if self.relu else ACT_NONE
+        if self.deconv:
+            return Deconv3dPlan(self.conv.weight, bn, act=act, eps=self.bn.eps)
+        return Conv3dPlan(self.conv.weight, bn, stride=self.conv.stride[0], act=act, eps=self.bn.eps)
+
+    def forward(self, x):
+        if self.is_3d:
+            raise _lib.DiffuVolumeError("3-D BasicConv runs through its HIP plan, not nn.Module.forward")
+        x = self.conv(x)
+        if self.use_bn:
+            x = self.bn(x)
+        return F.leaky_relu(x, 0.01) if self.relu else x
+
+
+class FeatureAtt(nn.Module):
+    """core/submodule.py:226-239: image-feature guided channel gate of a cost volume."""
+
+    def __init__(self, cv_chan, feat_chan):
+        super().__init__()
+        self.feat_att = nn.Sequential(BasicConv(feat_chan, feat_chan // 2, kernel_size=1, stride=1, padding=0),
+                                      nn.Conv2d(feat_chan // 2, cv_chan, 1))
+
+    def forward(self, cv, feat, inplace=False):
+        return feature_gate(cv, self.feat_att(feat), inplace=inplace)
+
+
+def _seq_plans(seq):
+    return [m.plan() for m in seq]
+
+
+def _run(plans, x):
+    for p in plans:
+        x = p(x)
+    return x
+
+
+class hourglass(nn.Module):
+    """igev_stereo_ddim.py:24-91 (`hourglass(8)`, runs once per pair on the gated gwc volume)."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        c = in_channels
+        k3 = dict(is_3d=True, bn=True, relu=True, kernel_size=3, padding=1, dilation=1)
+        self.conv1 = nn.Sequential(BasicConv(c, c * 2, stride=2, **k3), BasicConv(c * 2, c * 2, stride=1, **k3))
+        self.conv2 = nn.Sequential(BasicConv(c * 2, c * 4, stride=2, **k3), BasicConv(c * 4, c * 4, stride=1, **k3))
+        self.conv3 = nn.Sequential(BasicConv(c * 4, c * 6, stride=2, **k3), BasicConv(c * 6, c * 6, stride=1, **k3))
+        up = dict(deconv=True, is_3d=True, kernel_size=(4, 4, 4), padding=(1, 1, 1), stride=(2, 2, 2))
+        self.conv3_up = BasicConv(c * 6, c * 4, bn=True, relu=True, **up)
+        self.conv2_up = BasicConv(c * 4, c * 2, bn=True, relu=True, **up)
+        self.conv1_up = BasicConv(c * 2, 8, bn=False, relu=False, **up)
+
+        def agg(cin, cout):
+            return nn.Sequential(BasicConv(cin, cout, is_3d=True, kernel_size=1, padding=0, stride=1),
+                                 BasicConv(cout, cout, is_3d=True, kernel_size=3, padding=1, stride=1),
+                                 BasicConv(cout, cout, is_3d=True, kernel_size=3, padding=1, stride=1))
+
+        self.agg_0 = agg(c * 8, c * 4)
+        self.agg_1 = agg(c * 4, c * 2)
+        self.feature_att_8 = FeatureAtt(c * 2, 64)
+        self.feature_att_16 = FeatureAtt(c * 4, 192)
+        self.feature_att_32 = FeatureAtt(c * 6, 160)
+        self.feature_att_up_16 = FeatureAtt(c * 4, 192)
+        self.feature_att_up_8 = FeatureAtt(c * 2, 64)
+        self._plans = None
+
+    def prepare(self):
+        if self._plans is None:
+            self._plans = {n: _seq_plans(getattr(self, n)) for n in ("conv1", "conv2", "conv3", "agg_0", "agg_1")}
+            for n in ("conv3_up", "conv2_up", "conv1_up"):
+                self._plans[n] = getattr(self, n).plan()
+        return self._plans
+
+    def _apply(self, fn, *a, **k):
+        self._plans = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._plans = None
+        return super().load_state_dict(*a, **k)
+
+    def forward(self, x, features):
+        p = self.prepare()
+        conv1 = self.feature_att_8(_run(p["conv1"], x), features[1], inplace=True)
+        conv2 = self.feature_att_16(_run(p["conv2"], conv1), features[2], inplace=True)
+        conv3 = self.feature_att_32(_run(p["conv3"], conv2), features[3], inplace=True)
+        conv2 = _run(p["agg_0"], torch.cat((p["conv3_up"](conv3), conv2), dim=1))
+        conv2 = self.feature_att_up_16(conv2, features[2], inplace=True)
+        conv1 = _run(p["agg_1"], torch.cat((p["conv2_up"](conv2), conv1), dim=1))
+        conv1 = self.feature_att_up_8(conv1, features[1], inplace=True)
+        return p["conv1_up"](conv1)
+
+
+class IGEVCostVolume(nn.Module):
+    """The volume-side modules of IGEVStereo_ddim (:196-199) and the part of its forward that uses them
+    (:377-386).  ``forward(match_left, match_right, features_left)`` returns the geometry encoding volume
+    [B,8,D/4,h,w] (what Combined_Geo_Encoding_Volume filters at every GRU iteration) and `init_disp`
+    [B,1,h,w]."""
+
+    def __init__(self, max_disp: int = 192):
+        super().__init__()
+        self.max_disp = max_disp
+        self.corr_stem = BasicConv(8, 8, is_3d=True, kernel_size=3, stride=1, padding=1)
+        self.corr_feature_att = FeatureAtt(8, 96)
+        self.cost_agg = hourglass(8)
+        self.classifier = nn.Conv3d(8, 1, 3, 1, 1, bias=False)
+        self._plans = None
+
+    def _apply(self, fn, *a, **k):
+        self._plans = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._plans = None
+        return super().load_state_dict(*a, **k)
+
+    def prepare(self):
+        if self._plans is None:
+            self._plans = (self.corr_stem.plan(), Conv3dPlan(self.classifier.weight, None, stride=1, act=ACT_NONE))
+        return self._plans
+
+    def forward(self, match_left, match_right, features_left):
+        stem, classifier = self.prepare()
+        d4 = self.max_disp // 4
+        gwc = stem(build_gwc_volume(match_left, match_right, d4, 8))
+        gwc = self.corr_feature_att(gwc, features_left[0], inplace=True)
+        geo = self.cost_agg(gwc, features_left)
+        cost = classifier(geo)
+        return geo, softmax_regress(cost).unsqueeze(1)          # F.softmax + disparity_regression :382-383

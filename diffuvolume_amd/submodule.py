@@ -17,7 +17,7 @@ from .profiling import timed
 
 __all__ = ["build_gwc_volume", "build_concat_volume", "build_concat_attention_volume",
            "disparity_regression", "upsample_softmax_regress", "Conv3dPlan", "Deconv3dPlan",
-           "window_attention", "ACT_NONE", "ACT_RELU", "ACT_MISH", "ACT_LEAKY"]
+           "window_attention", "feature_gate", "softmax_regress", "ACT_NONE", "ACT_RELU", "ACT_MISH", "ACT_LEAKY"]
 
 ACT_NONE, ACT_RELU, ACT_MISH, ACT_LEAKY = 0, 1, 2, 3
 
@@ -173,6 +173,24 @@ def upsample_softmax_regress(cost: torch.Tensor, want_uncertainty: bool = True,
     return disp, unc
 
 
+def softmax_regress(cost: torch.Tensor) -> torch.Tensor:
+    """`disparity_regression(F.softmax(cost, 1), D)` without upsampling (igev_stereo_ddim.py:382-383):
+    cost [B,1,D,H,W] or [B,D,H,W] -> [B,H,W]."""
+    cost = _dev_f32(cost, "cost")
+    if cost.dim() == 5:
+        if cost.shape[1] != 1:
+            raise RuntimeError("cost must have one channel")
+        cost = cost[:, 0]
+    b, d, h, w = cost.shape
+    disp = torch.empty((b, h, w), dtype=torch.float32, device=cost.device)
+    lib = _lib.load()
+    with torch.cuda.device(cost.device):
+        timed("softmax_regress", 0.0, 4.0 * (cost.numel() + disp.numel()),
+              lambda: _lib.check(lib.dv_softmax_regress_f32(cost.data_ptr(), disp.data_ptr(), b, d, h, w,
+                                                            _lib.stream_ptr()), "dv_softmax_regress_f32"))
+    return disp
+
+
 class Conv3dPlan:
     """A Conv3d(bias=False)[+BatchNorm3d eval][+activation] layer prepared for the
     implicit-GEMM kernel: weights repacked once on the device, BN folded to a
@@ -311,6 +329,23 @@ def _fold_bn(bn, bias, cout, device, eps):
     if bias is not None:
         shift = shift + bias.detach().to(device=device, dtype=torch.float32) * scale
     return scale.contiguous(), shift.contiguous()
+
+
+def feature_gate(cv: torch.Tensor, logit: torch.Tensor, inplace: bool = False) -> torch.Tensor:
+    """`torch.sigmoid(feat_att) * cv` of FeatureAtt.forward (KITTI15/core/submodule.py:234-239); logit is the
+    2-D branch's output [B,C,H,W] before the sigmoid, cv the volume [B,C,D,H,W]."""
+    cv = _dev_f32(cv, "cv")
+    logit = _dev_f32(logit, "logit")
+    b, c, d, h, w = cv.shape
+    if tuple(logit.shape) != (b, c, h, w):
+        raise RuntimeError(f"gate logits {tuple(logit.shape)} do not match volume {tuple(cv.shape)}")
+    out = cv if inplace else torch.empty_like(cv)
+    lib = _lib.load()
+    with torch.cuda.device(cv.device):
+        timed("feature_gate", float(cv.numel()), 8.0 * cv.numel(),
+              lambda: _lib.check(lib.dv_feature_gate_f32(cv.data_ptr(), logit.data_ptr(), out.data_ptr(), b, c, d, h, w,
+                                                         _lib.stream_ptr()), "dv_feature_gate_f32"))
+    return out
 
 
 def window_attention(x: torch.Tensor, qkv_w: torch.Tensor, qkv_b: torch.Tensor, proj_w: torch.Tensor,

@@ -116,6 +116,11 @@ int dv_deconv3d_k4s2_f32(const float* in, const float* wpacked, const float* ch_
                          const float* ch_bias, const float* residual, float* out,
                          int B, int Cin, int D, int H, int W, int Cout, int act, dv_stream_t stream);
 
+/* FeatureAtt.forward's broadcast product (KITTI15/core/submodule.py:234-239):
+ * out[b,c,d,y,x] = sigmoid(logit[b,c,y,x]) * cv[b,c,d,y,x]; out may alias cv. */
+int dv_feature_gate_f32(const float* cv /*[B,C,D,H,W]*/, const float* logit /*[B,C,H,W]*/, float* out,
+                        int B, int C, int D, int H, int W, dv_stream_t stream);
+
 /* attention_block.forward: SceneFlow/models/submodule.py:398-429 -- 4x4x4 window
  * multi-head self-attention (heads x C/heads), qkv Linear(C,3C)+bias, softmax,
  * final 1x1x1 Conv3d(C,C)+bias.  x [B,C,D,H,W] -> out same shape.  D must be a
@@ -144,6 +149,10 @@ int dv_upsample_softmax_uncertainty_f32(const float* cost, const float* disp, fl
  * prob [B,D,H,W] -> disp [B,H,W]. */
 int dv_disparity_regression_f32(const float* prob, float* disp, int B, int D, int H, int W,
                                 dv_stream_t stream);
+
+/* F.softmax(dim=1) + disparity_regression at the volume's own resolution (IGEV init_disp,
+ * KITTI15/core/igev_stereo_ddim.py:382-383): cost [B,D,H,W] -> disp [B,H,W]. */
+int dv_softmax_regress_f32(const float* cost, float* disp, int B, int D, int H, int W, dv_stream_t stream);
 
 /* two-hot encoding of a quarter-resolution disparity (acv_ddim.py:403-419):
  * disp_q [B,h*w] -> x [B,nbins,h*w] = 2*twohot-1. */

@@ -130,3 +130,63 @@ class IGEVLoopOracle:
             img = torch.where(mask.unsqueeze(1) == 0, fill, img)
         stack = torch.cat(final, dim=1)                                  # [B, S+1, H, W]
         return (stack * torch.tensor(self.cof).view(1, -1, 1, 1)).sum(dim=1)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Cost-volume front of IGEVStereo_ddim.forward (KITTI15/core/igev_stereo_ddim.py:377-386): a functional
+# restatement over a flat state_dict, eval-mode BatchNorm.  Test infrastructure only.
+# ---------------------------------------------------------------------------------------------------
+def basic_conv(x, sd, p, *, is_3d, deconv=False, bn=True, relu=True, stride=1, padding=0):
+    """BasicConv.forward (core/submodule.py:29-35): conv(bias=False) -> [BN eval] -> [LeakyReLU(0.01)]."""
+    w = sd[p + ".conv.weight"]
+    if is_3d:
+        x = F.conv_transpose3d(x, w, None, stride, padding) if deconv else F.conv3d(x, w, None, stride, padding)
+    else:
+        x = F.conv2d(x, w, None, stride, padding)
+    if bn:
+        x = F.batch_norm(x, sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"], sd[p + ".bn.weight"],
+                         sd[p + ".bn.bias"], False, 0.0, 1e-5)
+    return F.leaky_relu(x, 0.01) if relu else x
+
+
+def feature_att(cv, feat, sd, p):
+    """FeatureAtt.forward (core/submodule.py:234-239)."""
+    a = basic_conv(feat, sd, p + ".feat_att.0", is_3d=False)
+    a = F.conv2d(a, sd[p + ".feat_att.1.weight"], sd[p + ".feat_att.1.bias"])
+    return torch.sigmoid(a).unsqueeze(2) * cv
+
+
+def igev_hourglass(x, features, sd, p="cost_agg"):
+    """hourglass.forward (igev_stereo_ddim.py:67-91)."""
+    def pair(t, name, stride):
+        t = basic_conv(t, sd, f"{p}.{name}.0", is_3d=True, stride=stride, padding=1)
+        return basic_conv(t, sd, f"{p}.{name}.1", is_3d=True, stride=1, padding=1)
+
+    def agg(t, name):
+        t = basic_conv(t, sd, f"{p}.{name}.0", is_3d=True)
+        t = basic_conv(t, sd, f"{p}.{name}.1", is_3d=True, padding=1)
+        return basic_conv(t, sd, f"{p}.{name}.2", is_3d=True, padding=1)
+
+    def up(t, name, bn=True, relu=True):
+        return basic_conv(t, sd, f"{p}.{name}", is_3d=True, deconv=True, bn=bn, relu=relu, stride=2, padding=1)
+
+    conv1 = feature_att(pair(x, "conv1", 2), features[1], sd, p + ".feature_att_8")
+    conv2 = feature_att(pair(conv1, "conv2", 2), features[2], sd, p + ".feature_att_16")
+    conv3 = feature_att(pair(conv2, "conv3", 2), features[3], sd, p + ".feature_att_32")
+    conv2 = agg(torch.cat((up(conv3, "conv3_up"), conv2), dim=1), "agg_0")
+    conv2 = feature_att(conv2, features[2], sd, p + ".feature_att_up_16")
+    conv1 = agg(torch.cat((up(conv2, "conv2_up"), conv1), dim=1), "agg_1")
+    conv1 = feature_att(conv1, features[1], sd, p + ".feature_att_up_8")
+    return up(conv1, "conv1_up", bn=False, relu=False)
+
+
+def igev_cost_volume(match_left, match_right, features_left, sd, max_disp=192):
+    """igev_stereo_ddim.py:377-383: (geo_encoding_volume [B,8,D/4,h,w], init_disp [B,1,h,w])."""
+    from .acv_oracle import build_gwc_volume, disparity_regression
+    d4 = max_disp // 4
+    gwc = build_gwc_volume(match_left, match_right, d4, 8)
+    gwc = basic_conv(gwc, sd, "corr_stem", is_3d=True, padding=1)
+    gwc = feature_att(gwc, features_left[0], sd, "corr_feature_att")
+    geo = igev_hourglass(gwc, features_left, sd, "cost_agg")
+    prob = F.softmax(F.conv3d(geo, sd["classifier.weight"], None, 1, 1).squeeze(1), dim=1)
+    return geo, disparity_regression(prob, d4, keepdim=True)

@@ -10,6 +10,8 @@
 // convolution, but each tap accumulates into its class's accumulator.  A block owns a
 // 2 x 2 x 32 brick of INPUT positions (= 4 x 4 x 64 outputs) and 32 output channels; each wave
 // one input row, all 8 classes.  No zero-stuffing, no wasted MFMA work.
+#include <type_traits>
+
 #include "dv_common.h"
 
 namespace {
@@ -40,7 +42,7 @@ __host__ __device__ constexpr int tap_off(int k) { return (k == 0 ? 1 : 0) - (k 
 
 struct DeconvArgs {
   const float* in;
-  const float* wpk;  // [Cinp/2][K^3][Coutp][2]
+  const float* wpk;  // see pack_deconv_weights_kernel
   const float* ch_scale;
   const float* ch_bias;
   const float* residual;  // [B,Cout,2D,2H,2W] or null
@@ -49,16 +51,28 @@ struct DeconvArgs {
   int ntx, nty, ntz, nco;
   int act;
   int vec_store;
+  int fast_ok;             // host-side part of the fast-epilogue condition (alignment, 32-bit offsets)
 };
+
+template <int N> struct VecOf;
+template <> struct VecOf<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct VecOf<4> { typedef float type __attribute__((ext_vector_type(4))); };
+
+template <int ACT>
+__device__ __forceinline__ float act_c(float v) { return dv_act(v, ACT); }
 
 template <int K, int KC_>
 __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
   using G = DGeo<K, KC_>;
   constexpr int kKC = G::KC, kT = G::T, kIY = G::IY, kIX = G::IX, kPRAW = G::PRAW, kP = G::P, LO = G::LO;
+  constexpr int NKS = kKC / 4;                     // k-steps (4 input channels each) per chunk
+  constexpr int BV = NKS * kNT;                    // B floats per lane and tap: [ks][n]
+  typedef typename VecOf<BV>::type bvec;
   __shared__ __attribute__((aligned(16))) float smem[G::IN_FLOATS + G::W_FLOATS];
   float* in_s = smem;
   float* w_s = smem + G::IN_FLOATS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: row bases below stay in SGPRs
   const int j = lane & 15, kq = lane >> 4;
 
   unsigned t = dv_xcd_remap(blockIdx.x, gridDim.x);
@@ -78,53 +92,57 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
 #pragma unroll
       for (int n = 0; n < kNT; ++n) acc[m][c][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int abase = kq * kP + ((zl + LO) * kIY + yl + LO) * kIX + j + LO;
-  const int bbase = ((kq >> 1) * kT * kCOUT + j) * 2 + (kq & 1);
+  const float* arow0 = in_s + kq * kP + ((zl + LO) * kIY + yl + LO) * kIX + j + LO;
+  const float* brow0 = w_s + lane * BV;          // LDS weights: [tap][kq][j][ks][n] -> one vector read per tap
   const size_t plane = (size_t)a.H * a.W, vol = (size_t)a.D * plane;
   const float* inb = a.in + (size_t)b * a.Cin * vol;
 
-  // staging plan (same scheme as conv3d.hip): each thread owns NS positions of the haloed input
-  // brick; the next chunk's global loads are issued before the current chunk's MFMA stream
+  // staging plan (as conv3d.hip): each thread owns NS positions of the haloed input brick, addressed as
+  // scalar channel base + 32-bit byte offset (0 and a zero mask outside the volume: no divergent loads);
+  // the next chunk's global loads are issued before the current chunk's MFMA stream
   constexpr int NS = (kPRAW + 255) / 256;
-  constexpr int ROWQ = kCOUT * 2 / 4;
-  constexpr int NQ = (kKC / 2) * kT * ROWQ;
+  constexpr int NQ = G::W_FLOATS / 4;
   constexpr int NWQ = (NQ + 255) / 256;
-  int sp[NS];
+  static_assert(kP > kPRAW, "need a pad slot per channel plane");
+  unsigned sob[NS];
+  bool sok[NS];
+  int wslot[NS];        // LDS slot of that position; threads past the brick write the plane's pad slot
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
     const int r = tid + 256 * i;
     const int zz = r / (kIY * kIX), r2 = r - zz * (kIY * kIX);
     const int yy = r2 / kIX, xx = r2 - yy * kIX;
     const int z = z0 - LO + zz, y = y0 - LO + yy, x = x0 - LO + xx;
-    sp[i] = (r < kPRAW && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
-                ? (z * a.H + y) * a.W + x : -1;
+    const bool ok = r < kPRAW && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+    sob[i] = ok ? (unsigned)((z * a.H + y) * a.W + x) * 4u : 0u;
+    sok[i] = ok;
+    wslot[i] = r < kPRAW ? r : kP - 1;
   }
   float vin[kKC][NS];
   f32x4 vw[NWQ];
-  auto fetch = [&](int c0) {
+  const int nchunk = (a.Cin + kKC - 1) / kKC;
+  auto fetch = [&](int c) {
 #pragma unroll
     for (int cl = 0; cl < kKC; ++cl) {
-      const float* src = inb + (size_t)(c0 + cl) * vol;
-      const bool cok = (c0 + cl) < a.Cin;
+      const int ch = c * kKC + cl;
+      const char* src = reinterpret_cast<const char*>(inb + (size_t)(ch < a.Cin ? ch : 0) * vol);
 #pragma unroll
-      for (int i = 0; i < NS; ++i) vin[cl][i] = (cok && sp[i] >= 0) ? src[sp[i]] : 0.f;
+      for (int i = 0; i < NS; ++i) vin[cl][i] = *reinterpret_cast<const float*>(src + sob[i]);
     }
-    const float* wsrc = a.wpk + ((size_t)(c0 >> 1) * kT * a.Coutp + co0) * 2;
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpk + ((size_t)c * a.nco + tc) * G::W_FLOATS);
 #pragma unroll
     for (int q = 0; q < NWQ; ++q) {
       const int e = tid + 256 * q;
-      const int row = e / ROWQ, qq = e - row * ROWQ;
-      if (e < NQ) vw[q] = reinterpret_cast<const f32x4*>(wsrc + (size_t)row * a.Coutp * 2)[qq];
+      if (e < NQ) vw[q] = wsrc[e];
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int c) {   // zero padding is applied here, not at the load: nothing may depend on a load in flight
 #pragma unroll
-    for (int cl = 0; cl < kKC; ++cl)
+    for (int cl = 0; cl < kKC; ++cl) {
+      const bool cok = (c * kKC + cl) < a.Cin;
 #pragma unroll
-      for (int i = 0; i < NS; ++i) {
-        const int r = tid + 256 * i;
-        if (r < kPRAW) in_s[cl * kP + r] = vin[cl][i];
-      }
+      for (int i = 0; i < NS; ++i) in_s[cl * kP + wslot[i]] = (cok && sok[i]) ? vin[cl][i] : 0.f;
+    }
 #pragma unroll
     for (int q = 0; q < NWQ; ++q) {
       const int e = tid + 256 * q;
@@ -132,34 +150,59 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
     }
   };
 
+  // input offsets a tap can ask for per dimension: K=3 -> {0,+1}, K=4 -> {-1,0,+1}
+  constexpr int OMIN = (K == 4) ? -1 : 0, NOFF = (K == 4) ? 3 : 2, NOZ = (K == 4) ? 1 : 2;
+
   fetch(0);
-  for (int c0 = 0; c0 < a.Cin; c0 += kKC) {
+  for (int c = 0; c < nchunk; ++c) {
     __syncthreads();
-    commit();
+    commit(c);
     __syncthreads();
-    if (c0 + kKC < a.Cin) fetch(c0 + kKC);
+    if (c + 1 < nchunk) fetch(c + 1);
+    // A fragments live in registers: every (z,y,x) input shift a tap can ask for x k-steps x M-tiles is read
+    // from LDS once (K=3: all 8 shifts per chunk; K=4: the 9 (y,x) shifts of one z shift, reloaded when kz
+    // changes slab), so the MFMA stream only needs one vector B read per tap, and that read is issued one tap
+    // ahead (sched_barrier keeps the compiler from sinking it back next to its use).
+    float av[NOZ][NOFF][NOFF][NKS][kMTX];
+    auto load_a = [&](int slot, int offz) {
 #pragma unroll
-    for (int kzy = 0; kzy < K * K; ++kzy) {
-      const int kz = kzy / K, ky = kzy - kz * K;
-      const float* arow = in_s + abase + (tap_off(kz) * kIY + tap_off(ky)) * kIX;
-      const float* brow = w_s + bbase + kzy * K * kCOUT * 2;
+      for (int oy = 0; oy < NOFF; ++oy)
 #pragma unroll
-      for (int kx = 0; kx < K; ++kx) {
-        const int cls = (tap_par(kz) << 2) | (tap_par(ky) << 1) | tap_par(kx);
+        for (int ox = 0; ox < NOFF; ++ox)
 #pragma unroll
-        for (int ks = 0; ks < kKC / 4; ++ks) {
-          float bf[kNT];
+          for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-          for (int n = 0; n < kNT; ++n) bf[n] = brow[((ks * 2 * kT + kx) * kCOUT + n * 16) * 2];
+            for (int m = 0; m < kMTX; ++m)
+              av[slot][oy][ox][ks][m] = arow0[(offz * kIY + OMIN + oy) * kIX + OMIN + ox + ks * 4 * kP + m * 16];
+    };
+    if (NOZ > 1) {
 #pragma unroll
-          for (int m = 0; m < kMTX; ++m) {
-            const float av = arow[m * 16 + ks * 4 * kP + tap_off(kx)];
+      for (int oz = 0; oz < NOZ; ++oz) load_a(oz, OMIN + oz);
+    }
+    bvec bq[2];
+    bq[0] = *reinterpret_cast<const bvec*>(brow0);
 #pragma unroll
-            for (int n = 0; n < kNT; ++n)
-              acc[m][cls][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bf[n], acc[m][cls][n], 0, 0, 0);
-          }
+    for (int kz = 0; kz < K; ++kz) {
+      if (NOZ == 1 && (kz == 0 || tap_off(kz) != tap_off(kz - 1))) load_a(0, tap_off(kz));
+      const int zs = NOZ > 1 ? tap_off(kz) - OMIN : 0;
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          const int tap = (kz * K + ky) * K + kx;
+          const int cls = (tap_par(kz) << 2) | (tap_par(ky) << 1) | tap_par(kx);
+          if (tap + 1 < kT) bq[(tap + 1) & 1] = *reinterpret_cast<const bvec*>(brow0 + (tap + 1) * 64 * BV);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int m = 0; m < kMTX; ++m)
+#pragma unroll
+              for (int n = 0; n < kNT; ++n)
+                acc[m][cls][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                    av[zs][tap_off(ky) - OMIN][tap_off(kx) - OMIN][ks][m], bq[tap & 1][ks * kNT + n], acc[m][cls][n], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
-      }
     }
   }
 
@@ -168,61 +211,155 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
   const size_t oplane = (size_t)Ho * Wo, ovol = (size_t)Do * oplane;
   const int zi = z0 + zl, yi = y0 + yl;
   if (zi >= a.D || yi >= a.H) return;
+  // Fast path (interior tiles, 16-byte aligned rows): everything address-like is either a scalar row base or
+  // one of four precomputed 32-bit lane offsets, so an output row costs 4 packed FMAs, the activation and two
+  // 16-byte stores -- the epilogue is issue-bound (it shares its SIMD with another block's MFMA stream).
+  const bool fast = a.fast_ok && co0 + kCOUT <= a.Cout && x0 + kTW <= a.W;
+  // ReLU / LeakyReLU / identity are max(v, slope * v) with slope 0 / 0.01 / 1; Mish has its own variant.
+  const float slope = a.act == DV_ACT_RELU ? 0.f : (a.act == DV_ACT_LEAKY ? 0.01f : 1.f);
+  auto epilogue_fast = [&](auto mishc, auto resc) __attribute__((always_inline)) {
+    constexpr bool MISH = decltype(mishc)::value;
+    constexpr bool RES = decltype(resc)::value;
+    unsigned loff[kNT][kMTX];
+    float sc[kNT], bi[kNT];
 #pragma unroll
-  for (int n = 0; n < kNT; ++n) {
-    const int co = co0 + n * 16 + j;
-    if (co >= a.Cout) continue;
-    const float sc = a.ch_scale ? a.ch_scale[co] : 1.f;
-    const float bi = a.ch_bias ? a.ch_bias[co] : 0.f;
-    const size_t cbase = ((size_t)b * a.Cout + co) * ovol;
+    for (int n = 0; n < kNT; ++n) {
+      const int co = co0 + n * 16 + j;
+      sc[n] = a.ch_scale ? a.ch_scale[co] : 1.f;
+      bi[n] = a.ch_bias ? a.ch_bias[co] : 0.f;
 #pragma unroll
-    for (int m = 0; m < kMTX; ++m) {
-      const int xi = x0 + m * 16 + 4 * kq;
-      if (xi >= a.W) continue;
+      for (int m = 0; m < kMTX; ++m)
+        loff[n][m] = (unsigned)(((size_t)co * ovol + 2 * (x0 + m * 16 + 4 * kq)) * sizeof(float));
+    }
+    const size_t bbase = (size_t)b * a.Cout * ovol;
+    auto rowo = [&](int k) {   // scalar offset of output row (pz, py) = (k >> 1, k & 1)
+      return bbase + (size_t)(2 * zi + (k >> 1)) * oplane + (size_t)(2 * yi + (k & 1)) * Wo;
+    };
+    // step q = (row k, channel half n); skip values are requested RD-1 steps ahead (16 registers per buffer)
+    constexpr int RD = (K == 3) ? 3 : 2;   // ring of skip-value buffers: step q+RD-1 is in flight while step q is stored
+    f32x4 rv[RES ? RD : 1][kMTX][2];
+    auto load_res = [&](int q) __attribute__((always_inline)) {
+      const char* rrow = reinterpret_cast<const char*>(a.residual + rowo(q >> 1));
 #pragma unroll
-      for (int pz = 0; pz < 2; ++pz)
+      for (int m = 0; m < kMTX; ++m) {
+        rv[q % RD][m][0] = *reinterpret_cast<const f32x4*>(rrow + loff[q & 1][m]);
+        rv[q % RD][m][1] = *reinterpret_cast<const f32x4*>(rrow + loff[q & 1][m] + 16);
+      }
+    };
+    if (RES) {
 #pragma unroll
-        for (int py = 0; py < 2; ++py) {
-          const size_t o = cbase + (size_t)(2 * zi + pz) * oplane + (size_t)(2 * yi + py) * Wo + 2 * xi;
-          const f32x4 e0 = acc[m][(pz << 2) | (py << 1)][n], e1 = acc[m][(pz << 2) | (py << 1) | 1][n];
-          float v[8] = {e0[0], e1[0], e0[1], e1[1], e0[2], e1[2], e0[3], e1[3]};
+      for (int q = 0; q < RD - 1; ++q) load_res(q);
+    }
 #pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] = fmaf(v[r], sc, bi);
-          if (a.vec_store) {  // W % 4 == 0 here, so all 8 outputs are in range
-            if (a.residual) {
-              const float4 r0 = *reinterpret_cast<const float4*>(a.residual + o);
-              const float4 r1 = *reinterpret_cast<const float4*>(a.residual + o + 4);
-              v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
-              v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-            }
-            *reinterpret_cast<float4*>(a.out + o) = make_float4(
-                dv_act(v[0], a.act), dv_act(v[1], a.act), dv_act(v[2], a.act), dv_act(v[3], a.act));
-            *reinterpret_cast<float4*>(a.out + o + 4) = make_float4(
-                dv_act(v[4], a.act), dv_act(v[5], a.act), dv_act(v[6], a.act), dv_act(v[7], a.act));
-          } else {
+    for (int q = 0; q < 4 * kNT; ++q) {
+      static_assert(kNT == 2, "q & 1 is the channel half");
+      const int k = q >> 1, n = q & 1;
+      if (RES && q + RD - 1 < 4 * kNT) load_res(q + RD - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      char* orow = reinterpret_cast<char*>(a.out + rowo(k));
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
-              if (2 * xi + r < Wo) {
-                float u = v[r];
-                if (a.residual) u += a.residual[o + r];
-                a.out[o + r] = dv_act(u, a.act);
-              }
-          }
+      for (int m = 0; m < kMTX; ++m) {
+        const f32x4 e0 = acc[m][k << 1][n], e1 = acc[m][(k << 1) | 1][n];
+        f32x4 lo = {e0[0], e1[0], e0[1], e1[1]}, hi = {e0[2], e1[2], e0[3], e1[3]};
+        lo = lo * sc[n] + bi[n];
+        hi = hi * sc[n] + bi[n];
+        if (RES) {
+          lo += rv[q % RD][m][0];
+          hi += rv[q % RD][m][1];
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          lo[r] = MISH ? dv_act(lo[r], DV_ACT_MISH) : fmaxf(lo[r], lo[r] * slope);
+          hi[r] = MISH ? dv_act(hi[r], DV_ACT_MISH) : fmaxf(hi[r], hi[r] * slope);
+        }
+        *reinterpret_cast<f32x4*>(orow + loff[n][m]) = lo;
+        *reinterpret_cast<f32x4*>(orow + loff[n][m] + 16) = hi;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (fast) {
+    if (a.act == DV_ACT_MISH) {
+      if (a.residual) epilogue_fast(std::true_type{}, std::true_type{});
+      else epilogue_fast(std::true_type{}, std::false_type{});
+    } else {
+      if (a.residual) epilogue_fast(std::false_type{}, std::true_type{});
+      else epilogue_fast(std::false_type{}, std::false_type{});
+    }
+  }
+  auto epilogue = [&](auto actc) __attribute__((always_inline)) {
+    constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+    for (int n = 0; n < kNT; ++n) {
+      const int co = co0 + n * 16 + j;
+      if (co >= a.Cout) continue;
+      const float sc = a.ch_scale ? a.ch_scale[co] : 1.f;
+      const float bi = a.ch_bias ? a.ch_bias[co] : 0.f;
+      const size_t cbase = ((size_t)b * a.Cout + co) * ovol;
+#pragma unroll
+      for (int m = 0; m < kMTX; ++m) {
+        const int xi = x0 + m * 16 + 4 * kq;
+        if (xi >= a.W) continue;
+#pragma unroll
+        for (int pz = 0; pz < 2; ++pz)
+#pragma unroll
+          for (int py = 0; py < 2; ++py) {
+            const size_t o = cbase + (size_t)(2 * zi + pz) * oplane + (size_t)(2 * yi + py) * Wo + 2 * xi;
+            const f32x4 e0 = acc[m][(pz << 2) | (py << 1)][n], e1 = acc[m][(pz << 2) | (py << 1) | 1][n];
+            float v[8] = {e0[0], e1[0], e0[1], e1[1], e0[2], e1[2], e0[3], e1[3]};
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = fmaf(v[r], sc, bi);
+            if (a.vec_store) {  // W % 4 == 0 here, so all 8 outputs are in range
+              if (a.residual) {
+                const float4 r0 = *reinterpret_cast<const float4*>(a.residual + o);
+                const float4 r1 = *reinterpret_cast<const float4*>(a.residual + o + 4);
+                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+                v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+              }
+              *reinterpret_cast<float4*>(a.out + o) =
+                  make_float4(act_c<ACT>(v[0]), act_c<ACT>(v[1]), act_c<ACT>(v[2]), act_c<ACT>(v[3]));
+              *reinterpret_cast<float4*>(a.out + o + 4) =
+                  make_float4(act_c<ACT>(v[4]), act_c<ACT>(v[5]), act_c<ACT>(v[6]), act_c<ACT>(v[7]));
+            } else {
+#pragma unroll
+              for (int r = 0; r < 8; ++r)
+                if (2 * xi + r < Wo) {
+                  float u = v[r];
+                  if (a.residual) u += a.residual[o + r];
+                  a.out[o + r] = act_c<ACT>(u);
+                }
+            }
+          }
+      }
+    }
+  };
+  if (!fast) {
+    switch (a.act) {
+      case DV_ACT_RELU: epilogue(std::integral_constant<int, DV_ACT_RELU>{}); break;
+      case DV_ACT_MISH: epilogue(std::integral_constant<int, DV_ACT_MISH>{}); break;
+      case DV_ACT_LEAKY: epilogue(std::integral_constant<int, DV_ACT_LEAKY>{}); break;
+      default: epilogue(std::integral_constant<int, DV_ACT_NONE>{}); break;
     }
   }
 }
 
+// packed weights: [chunk = ci / KC][co block of 32][tap][kq = ci % 4][j = co % 16][ks = (ci % KC) / 4][n = (co % 32) / 16]
+// = exactly the order the kernel's LDS image wants, so staging is a straight 16-byte copy.
 __global__ void pack_deconv_weights_kernel(const float* __restrict__ w, float* __restrict__ wpk, int Cin,
-                                           int Cout, int Cinp, int Coutp, int kT) {
-  const size_t total = (size_t)Cinp * kT * Coutp;
+                                           int Cout, int nchunk, int nco, int kT, int KC) {
+  const int NKS = KC / 4;
+  const size_t total = (size_t)nchunk * nco * kT * 64 * NKS * kNT;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
-    const int par = (int)(i & 1);
-    size_t r = i >> 1;
-    const int co = (int)(r % Coutp); r /= Coutp;
-    const int tap = (int)(r % kT);
-    const int ci = (int)(r / kT) * 2 + par;
+    size_t r = i;
+    const int n = (int)(r % kNT); r /= kNT;
+    const int ks = (int)(r % NKS); r /= NKS;
+    const int j = (int)(r % 16); r /= 16;
+    const int kq = (int)(r % 4); r /= 4;
+    const int tap = (int)(r % kT); r /= kT;
+    const int tc = (int)(r % nco);
+    const int c = (int)(r / nco);
+    const int ci = c * KC + ks * 4 + kq, co = tc * kCOUT + n * 16 + j;
     wpk[i] = (ci < Cin && co < Cout) ? w[((size_t)ci * Cout + co) * kT + tap] : 0.f;
   }
 }
@@ -237,11 +374,13 @@ int launch_deconv(DeconvArgs a, hipStream_t s) {
   return dv_launch_status();
 }
 
+constexpr int kc_of(int K) { return K == 3 ? 8 : 4; }   // input channels per LDS chunk
+
 int pack_any(const float* w, float* wpacked, int Cin, int Cout, int K, hipStream_t s) {
-  const int T = K * K * K, Cinp = pad_to(Cin, 8), Coutp = pad_to(Cout, kCOUT);
-  const size_t total = (size_t)Cinp * T * Coutp;
+  const int T = K * K * K, KC = kc_of(K), nchunk = pad_to(Cin, 8) / KC, nco = pad_to(Cout, kCOUT) / kCOUT;
+  const size_t total = (size_t)nchunk * nco * T * KC * kCOUT;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(pack_deconv_weights_kernel, dim3(blocks), dim3(256), 0, s, w, wpacked, Cin, Cout, Cinp, Coutp, T);
+  hipLaunchKernelGGL(pack_deconv_weights_kernel, dim3(blocks), dim3(256), 0, s, w, wpacked, Cin, Cout, nchunk, nco, T, KC);
   return dv_launch_status();
 }
 
@@ -258,6 +397,9 @@ int run_any(const float* in, const float* wpacked, const float* ch_scale, const 
   a.nco = a.Coutp / kCOUT;
   a.act = act;
   a.vec_store = (W % 4 == 0) && dv_aligned16(out) && (!residual || dv_aligned16(residual));
+  if ((size_t)D * H * W * sizeof(float) > 0xffffffffull) return DV_ERR_SHAPE;   // 32-bit in-channel byte offsets
+  // fast epilogue: scalar row base + 32-bit per-lane byte offsets inside one batch item
+  a.fast_ok = a.vec_store && (size_t)Cout * 8 * D * H * W * sizeof(float) <= 0xffffffffull;
   return K == 3 ? launch_deconv<3, 8>(a, s) : launch_deconv<4, 4>(a, s);
 }
 

@@ -17,6 +17,8 @@ LAYERS = {  # name: (kind, cin, cout, k, stride, (D,H,W))
     "c128": ("conv", 128, 128, 3, 1, (12, 32, 60)),
     "dc128": ("deconv", 128, 64, 3, 2, (12, 32, 60)),
     "dc64": ("deconv", 64, 32, 3, 2, (24, 64, 120)),
+    "dc128r": ("deconv_res", 128, 64, 3, 2, (12, 32, 60)),
+    "dc64r": ("deconv_res", 64, 32, 3, 2, (24, 64, 120)),
     "k1_32": ("conv", 32, 32, 1, 1, (48, 128, 240)),
     "k1_64": ("conv", 64, 64, 1, 1, (24, 64, 120)),
 }
@@ -35,12 +37,17 @@ for n in names:
         w = torch.randn(cin, cout, 3, 3, 3, device=dev) * 0.05
         plan = S.Deconv3dPlan(w, bn, act=S.ACT_RELU)
         flops = 2.0 * B * cout * cin * 27 * dims[0] * dims[1] * dims[2]
-    y = plan(x)
+    if kind == "deconv_res":
+        res = torch.randn(B, cout, *(2 * d for d in dims), device=dev)
+        run = lambda: plan(x, residual=res)
+    else:
+        run = lambda: plan(x)
+    y = run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        y = plan(x)
+        y = run()
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters

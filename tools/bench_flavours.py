@@ -1,0 +1,101 @@
+"""Full-size timing of the KITTI12 (config 4) and KITTI15 (config 5, volume front + lookup) flavours on one GPU.
+Not a bench line (BASELINE.json: the other configs are parity cases); the numbers go to DESIGN.md section 5c.
+    python tools/bench_flavours.py [--pcw] [--igev]"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from diffuvolume_amd.profiling import KernelTimer  # noqa: E402
+from diffuvolume_amd.synth import _gen, synth_state_dict, synth_stereo_batch  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def timeit(fn, warmup=1, steps=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def kernels(fn):
+    kt = KernelTimer()
+    KernelTimer.active = kt
+    try:
+        fn()
+    finally:
+        KernelTimer.active = None
+    return {k: [v["launches"], round(v["total_ms"], 3), round(v["flops"] / max(v["total_ms"], 1e-9) / 1e9, 1)]
+            for k, v in kt.summary().items()}
+
+
+def pcw(b=4, h=384, w=1248):
+    from diffuvolume_amd.pwcnet_ddim import PWCNet_ddim
+    m = PWCNet_ddim(192, True)
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed=2, logit_gain=8.0, scale={"refinenet3.conv8.weight": 0.002}))
+    m = m.to(DEV).eval()
+    batch = {k: v.to(DEV) for k, v in synth_stereo_batch(b, h, w, seed=0).items()}
+    with torch.no_grad():
+        fl = m.feature_extraction(batch["left"] * 0.05)
+        fr = m.feature_extraction(batch["right"] * 0.05)
+        combine = m.fused_volume(fl, fr)
+        x_t = m.encode_disparity(batch["disp"])
+    res = {"config": f"KITTI12 PCWNet+DiffuVolume B={b} {w}x{h}, 3 DDIM steps"}
+    with torch.no_grad():
+        res["volume_build_ms"] = timeit(lambda: m.fused_volume(fl, fr))
+        res["ddim_sample_ms"] = timeit(lambda: m.ddim_sample(combine, batch["used"], x_t, fl, fr))
+        res["forward_ms"] = timeit(lambda: m(batch["left"] * 0.05, batch["right"] * 0.05, batch["used"], batch["disp"]))
+        res["ddim_sample_kernels_ms"] = kernels(lambda: m.ddim_sample(combine, batch["used"], x_t, fl, fr))
+    res["pairs_per_s_hot"] = b / ((res["volume_build_ms"] + res["ddim_sample_ms"]) / 1e3)
+    res["pairs_per_s_forward"] = b / (res["forward_ms"] / 1e3)
+    return res
+
+
+def igev(b=4, h=96, w=312):
+    from diffuvolume_amd.geometry_ddim import Combined_Geo_Encoding_Volume
+    from diffuvolume_amd.igev_stereo_ddim import IGEVCostVolume
+    m = IGEVCostVolume()
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed=91, logit_gain=60.0))
+    m = m.to(DEV).eval()
+    ml = torch.randn(b, 96, h, w, generator=_gen(5, "ml"))
+    mr = torch.roll(ml, -5, dims=-1) + 0.1 * torch.randn(b, 96, h, w, generator=_gen(5, "mr"))
+    feats = [torch.randn(b, c, h // s, w // s, generator=_gen(5, f"f{i}")).to(DEV)
+             for i, (c, s) in enumerate(((96, 1), (64, 2), (192, 4), (160, 8)))]
+    ml, mr = ml.to(DEV), mr.to(DEV)
+    res = {"config": f"KITTI15 IGEV cost-volume front B={b} 1/4 res {w}x{h}, D/4=48"}
+    with torch.no_grad():
+        res["front_ms"] = timeit(lambda: m(ml, mr, feats))
+        geo, init = m(ml, mr, feats)
+        fn = Combined_Geo_Encoding_Volume(ml, mr, geo, radius=4, num_levels=2)
+        coords = torch.arange(w, dtype=torch.float32, device=DEV).view(1, 1, 1, w).expand(b, 1, h, w).contiguous()
+        noisy = torch.rand(b, 48, h, w, device=DEV)
+        res["geo_lookup_ms"] = timeit(lambda: fn(init, coords, noisy), warmup=2, steps=20)
+        res["front_kernels_ms"] = kernels(lambda: m(ml, mr, feats))
+    res["lookups_per_pair_cfg5"] = "20 steps x 32 iters = 640 (reference default 2 x 32)"
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pcw", action="store_true")
+    ap.add_argument("--igev", action="store_true")
+    a = ap.parse_args()
+    out = {}
+    if a.igev or not (a.pcw or a.igev):
+        out["igev"] = igev()
+    if a.pcw or not (a.pcw or a.igev):
+        out["pcw"] = pcw()
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,363 @@
+// K11: 2-D convolution (3x3 with dilation 1..16, or 1x1; stride 1, "same" padding) + BatchNorm (eval) +
+// residual + Mish/ReLU/LeakyReLU, fp32 on v_mfma_f32_16x16x4_f32.  This is the per-DDIM-step disparity
+// refinement stack of the KITTI12 flavour: refinenet_version3 (KITTI12/models/pwcnet_ddim.py:251-306) built
+// from convbn (KITTI12/models/submodule.py:21-24, padding = dilation) and BasicBlock (:192-215, out += x
+// with no activation after the add).  At 1248x384 it is 0.85 TFLOP per pair and step.
+//
+// GEMM view (as conv3d.hip): M = 16 consecutive x of an output row, N = 16 cout, K = tap x cin.  A block owns
+// 8 rows x 64 columns x 32 (or 16) output channels; each wave 2 rows x 4 M-tiles.  Per chunk of KC input channels
+// the input rows the 9 taps can touch are staged in LDS:
+//   * dilation <= 4 ("contiguous"): the haloed brick (8+2d) x (64+2d);
+//   * dilation 5..16 ("banded"): three 8-row bands (one per ky, d rows apart) x (64+2d) -- a haloed brick would
+//     be (8+32) rows for 8 rows of output.
+// The dilation is a run-time value: all tap offsets are wave-uniform scalars added to one per-lane base.
+// Weights sit in LDS as [tap][quad][lane][4] so that a lane fetches the B fragments of a tap (all k-steps and
+// N tiles) with 16-byte reads; A fragments and the B vector of step s+1 are requested before the MFMAs of
+// step s (register double buffer, order pinned with sched_barrier); the next chunk's global loads are issued
+// one chunk ahead (as conv3d.hip).
+#include <type_traits>
+
+#include "dv_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int TH = 8, MTX = 4, TW = MTX * 16, RPW = 2, MT = RPW * MTX;
+
+__host__ __device__ constexpr int plane_pad(int n) {   // smallest p > n with p % 32 == 16 (bank rule + a spare slot)
+  return (n + 1) + ((16 - (n + 1) % 32) + 32) % 32;
+}
+
+template <int KS_, int NT_, int KC_, int DMAX_, bool BANDED_>
+struct G2 {
+  static constexpr int KS = KS_, NT = NT_, KC = KC_, DMAX = DMAX_;
+  static constexpr bool BANDED = BANDED_;
+  static constexpr int T = KS * KS, NKS = KC / 4, COUT = NT * 16;
+  static constexpr int BV = NKS * NT;                 // B floats per lane and tap: [ks][n]
+  static constexpr int VW = BV < 4 ? BV : 4;          // floats per LDS read
+  static constexpr int Q = BV / VW;
+  static constexpr int RMAX = BANDED ? 3 * TH : TH + (KS - 1) * DMAX;
+  static constexpr int CMAX = TW + (KS - 1) * DMAX;
+  static constexpr int PMAX = plane_pad(RMAX * CMAX);
+  static constexpr int IN_FLOATS = KC * PMAX, W_FLOATS = T * KC * COUT;
+  static_assert(BV == 1 || BV == 2 || BV % 4 == 0, "B vector width");
+  static_assert((IN_FLOATS + W_FLOATS) * 4 <= 80 * 1024, "two blocks per CU");
+};
+
+struct Conv2dArgs {
+  const float* in;        // [B,Cin,H,W]
+  const float* wpk;       // see pack_conv2d_weights_kernel
+  const float* ch_scale;  // [Cout] or null
+  const float* ch_bias;   // [Cout] or null
+  const float* residual;  // [B,Cout,H,W] or null
+  float* out;             // [B,Cout,H,W]
+  int B, Cin, H, W, Cout;
+  int dil;                // dilation (= padding); 0 for 1x1
+  int ntx, nty, nco;
+  int act, vec_store, fast_ok;
+};
+
+template <class G>
+__global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(Conv2dArgs a) {
+  constexpr int KS = G::KS, NT = G::NT, KC = G::KC, NKS = G::NKS, BV = G::BV, VW = G::VW, Q = G::Q, T = G::T;
+  __shared__ __attribute__((aligned(16))) float smem[G::IN_FLOATS + G::W_FLOATS];
+  float* in_s = smem;
+  float* w_s = smem + G::IN_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, kq = lane >> 4;
+
+  unsigned t = dv_xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = t % a.ntx; t /= a.ntx;
+  const int ty = t % a.nty; t /= a.nty;
+  const int tc = t % a.nco;
+  const int b = t / a.nco;
+  const int x0 = tx * TW, y0 = ty * TH, co0 = tc * G::COUT;
+  const int d = a.dil;
+  const int C = TW + (KS - 1) * d;                        // staged columns
+  const int R = G::BANDED ? 3 * TH : TH + (KS - 1) * d;   // staged rows
+  const int P = plane_pad(R * C);                         // channel plane stride in LDS (== 16 mod 32)
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const size_t plane = (size_t)a.H * a.W;
+  const float* inb = a.in + (size_t)b * a.Cin * plane;
+
+  // ---- staging plan: each thread owns NS positions of the staged rows (same for every channel) ----
+  constexpr int NS = (G::RMAX * G::CMAX + 255) / 256;
+  constexpr int NQ = G::W_FLOATS / 4, NWQ = (NQ + 255) / 256;
+  unsigned sob[NS];
+  bool sok[NS];
+  int wslot[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int r = tid + 256 * i;
+    const int row = r / C, col = r - row * C;
+    const int gy = G::BANDED ? y0 + (row / TH - 1) * d + row % TH : y0 - (KS / 2) * d + row;
+    const int gx = x0 - (KS / 2) * d + col;
+    const bool ok = r < R * C && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    sob[i] = ok ? (unsigned)(gy * a.W + gx) * 4u : 0u;
+    sok[i] = ok;
+    wslot[i] = r < R * C ? r : P - 1;     // threads past the brick write the plane's spare slot
+  }
+  float vin[KC][NS];
+  f32x4 vw[NWQ];
+  const int nchunk = (a.Cin + KC - 1) / KC;
+  auto fetch = [&](int c) {
+#pragma unroll
+    for (int cl = 0; cl < KC; ++cl) {
+      const int ch = c * KC + cl;
+      const char* src = reinterpret_cast<const char*>(inb + (size_t)(ch < a.Cin ? ch : 0) * plane);
+#pragma unroll
+      for (int i = 0; i < NS; ++i) vin[cl][i] = *reinterpret_cast<const float*>(src + sob[i]);
+    }
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpk + ((size_t)c * a.nco + tc) * G::W_FLOATS);
+#pragma unroll
+    for (int q = 0; q < NWQ; ++q) {
+      const int e = tid + 256 * q;
+      if (e < NQ) vw[q] = wsrc[e];
+    }
+  };
+  auto commit = [&](int c) {   // zero padding applied here: nothing may depend on a load in flight
+#pragma unroll
+    for (int cl = 0; cl < KC; ++cl) {
+      const bool cok = (c * KC + cl) < a.Cin;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) in_s[cl * P + wslot[i]] = (cok && sok[i]) ? vin[cl][i] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < NWQ; ++q) {
+      const int e = tid + 256 * q;
+      if (e < NQ) reinterpret_cast<f32x4*>(w_s)[e] = vw[q];
+    }
+  };
+
+  // step s = (tap, ks): 8 A fragments (2 rows x 4 M-tiles) + the tap's B vector
+  const float* abase = in_s + kq * P + (wave * RPW) * C + j;
+  const float* bbase = w_s + lane * VW;
+  auto load_a = [&](float (&av)[MT], int tap, int ks) __attribute__((always_inline)) {
+    const int ky = tap / KS, kx = tap - ky * KS;
+    const int off = (G::BANDED ? ky * TH : ky * d) * C + kx * d + ks * 4 * P;   // wave-uniform
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+      for (int xt = 0; xt < MTX; ++xt) av[r * MTX + xt] = abase[off + r * C + xt * 16];
+  };
+  auto load_b = [&](float (&bv)[BV], int tap) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const float* p = bbase + (tap * Q + q) * 64 * VW;
+      if constexpr (VW == 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[q * 4 + e] = v[e];
+      } else if constexpr (VW == 2) {
+        const f32x2 v = *reinterpret_cast<const f32x2*>(p);
+        bv[0] = v[0];
+        bv[1] = v[1];
+      } else {
+        bv[0] = p[0];
+      }
+    }
+  };
+
+  fetch(0);
+  for (int c = 0; c < nchunk; ++c) {
+    __syncthreads();
+    commit(c);
+    __syncthreads();
+    if (c + 1 < nchunk) fetch(c + 1);
+    float av[2][MT];
+    float bv[2][BV];
+    load_a(av[0], 0, 0);
+    load_b(bv[0], 0);
+#pragma unroll
+    for (int s = 0; s < T * NKS; ++s) {
+      const int tap = s / NKS, ks = s - tap * NKS;
+      if (s + 1 < T * NKS) {
+        load_a(av[(s + 1) & 1], (s + 1) / NKS, (s + 1) % NKS);
+        if ((s + 1) % NKS == 0) load_b(bv[((s + 1) / NKS) & 1], (s + 1) / NKS);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s & 1][m], bv[tap & 1][ks * NT + n], acc[m][n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue: BN scale/bias, residual, activation; lane = 4 x of one channel ----
+  const bool fast = a.fast_ok && co0 + G::COUT <= a.Cout && x0 + TW <= a.W && y0 + TH <= a.H;
+  const float slope = a.act == DV_ACT_RELU ? 0.f : (a.act == DV_ACT_LEAKY ? 0.01f : 1.f);
+  auto epilogue_fast = [&](auto mishc, auto resc) __attribute__((always_inline)) {
+    constexpr bool MISH = decltype(mishc)::value;
+    constexpr bool RES = decltype(resc)::value;
+    unsigned loff[NT];
+    float sc[NT], bi[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int co = co0 + n * 16 + j;
+      sc[n] = a.ch_scale ? a.ch_scale[co] : 1.f;
+      bi[n] = a.ch_bias ? a.ch_bias[co] : 0.f;
+      loff[n] = (unsigned)(((size_t)co * plane + x0 + 4 * kq) * sizeof(float));
+    }
+    const size_t bbase_o = (size_t)b * a.Cout * plane;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const size_t rowo = bbase_o + (size_t)(y0 + wave * RPW + r) * a.W;     // scalar
+      char* orow = reinterpret_cast<char*>(a.out + rowo);
+      const char* rrow = reinterpret_cast<const char*>(RES ? a.residual + rowo : nullptr);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        f32x4 rv[MTX];
+        if (RES) {
+#pragma unroll
+          for (int xt = 0; xt < MTX; ++xt) rv[xt] = *reinterpret_cast<const f32x4*>(rrow + loff[n] + xt * 64);
+        }
+#pragma unroll
+        for (int xt = 0; xt < MTX; ++xt) {
+          f32x4 v = acc[r * MTX + xt][n] * sc[n] + bi[n];
+          if (RES) v += rv[xt];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = MISH ? dv_act(v[e], DV_ACT_MISH) : fmaxf(v[e], v[e] * slope);
+          *reinterpret_cast<f32x4*>(orow + loff[n] + xt * 64) = v;
+        }
+      }
+    }
+  };
+  if (fast) {
+    if (a.act == DV_ACT_MISH) {
+      if (a.residual) epilogue_fast(std::true_type{}, std::true_type{});
+      else epilogue_fast(std::true_type{}, std::false_type{});
+    } else {
+      if (a.residual) epilogue_fast(std::false_type{}, std::true_type{});
+      else epilogue_fast(std::false_type{}, std::false_type{});
+    }
+    return;
+  }
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int co = co0 + n * 16 + j;
+    if (co >= a.Cout) continue;
+    const float sc = a.ch_scale ? a.ch_scale[co] : 1.f;
+    const float bi = a.ch_bias ? a.ch_bias[co] : 0.f;
+    const size_t cbase = ((size_t)b * a.Cout + co) * plane;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int yo = y0 + wave * RPW + m / MTX, xo = x0 + (m % MTX) * 16 + 4 * kq;
+      if (yo >= a.H || xo >= a.W) continue;
+      const size_t o = cbase + (size_t)yo * a.W + xo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (xo + e < a.W) {
+          float u = fmaf(acc[m][n][e], sc, bi);
+          if (a.residual) u += a.residual[o + e];
+          a.out[o + e] = dv_act(u, a.act);
+        }
+    }
+  }
+}
+
+// packed weights: [chunk = ci / KC][co block][tap][quad q][lane = kq*16 + j][VW floats], where element
+// e = ks * NT + n of the lane's B vector lives at quad e / VW, slot e % VW;  ci = chunk*KC + ks*4 + kq,
+// co = block*COUT + n*16 + j.  Exactly the LDS image, so staging is a straight 16-byte copy.
+__global__ void pack_conv2d_weights_kernel(const float* __restrict__ w, float* __restrict__ wpk, int Cin, int Cout,
+                                           int nchunk, int nco, int T, int KC, int NT) {
+  const int NKS = KC / 4, BV = NKS * NT, VW = BV < 4 ? BV : 4, Q = BV / VW;
+  const size_t total = (size_t)nchunk * nco * T * Q * 64 * VW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    size_t r = i;
+    const int slot = (int)(r % VW); r /= VW;
+    const int lane = (int)(r % 64); r /= 64;
+    const int q = (int)(r % Q); r /= Q;
+    const int tap = (int)(r % T); r /= T;
+    const int tc = (int)(r % nco);
+    const int c = (int)(r / nco);
+    const int e = q * VW + slot, ks = e / NT, n = e - ks * NT;
+    const int kq = lane >> 4, j = lane & 15;
+    const int ci = c * KC + ks * 4 + kq, co = (tc * NT + n) * 16 + j;
+    wpk[i] = (ci < Cin && co < Cout) ? w[((size_t)co * Cin + ci) * T + tap] : 0.f;
+  }
+}
+
+inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+
+// geometry choice: N tiles per block by Cout, chunk depth by what fits two blocks per CU
+// (NT = 4 would halve the staging traffic of the wide layers but needs 128 accumulator registers: it spills)
+inline int nt_of(int Cout) { return Cout > 16 ? 2 : 1; }
+inline int kc_of(int k, int dil) { return (k == 3 && dil > 4) ? 4 : 8; }
+
+template <class G>
+int launch2d(Conv2dArgs a, hipStream_t s) {
+  a.ntx = (a.W + TW - 1) / TW;
+  a.nty = (a.H + TH - 1) / TH;
+  a.nco = pad_to(a.Cout, G::COUT) / G::COUT;
+  const long long blocks = (long long)a.B * a.nco * a.nty * a.ntx;
+  if (blocks <= 0 || blocks > 0x7fffffffLL) return DV_ERR_SHAPE;
+  hipLaunchKernelGGL((conv2d_mfma_kernel<G>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+  return dv_launch_status();
+}
+
+}  // namespace
+
+extern "C" size_t dv_conv2d_packed_floats(int Cin, int Cout, int k, int dilation) {
+  if (Cin <= 0 || Cout <= 0 || (k != 1 && k != 3)) return 0;
+  const int KC = kc_of(k, dilation), NT = nt_of(Cout);
+  return (size_t)pad_to(Cin, KC) * (k * k) * pad_to(Cout, NT * 16);
+}
+
+extern "C" int dv_conv2d_pack_weights_f32(const float* w, float* wpacked, int Cin, int Cout, int k, int dilation,
+                                          dv_stream_t stream) {
+  DV_REQUIRE_PTR(w);
+  DV_REQUIRE_PTR(wpacked);
+  DV_REQUIRE(Cin > 0 && Cout > 0, DV_ERR_SHAPE);
+  DV_REQUIRE(k == 1 || k == 3, DV_ERR_UNSUPPORTED);
+  const int KC = kc_of(k, dilation), NT = nt_of(Cout);
+  const int nchunk = pad_to(Cin, KC) / KC, nco = pad_to(Cout, NT * 16) / (NT * 16);
+  const size_t total = (size_t)nchunk * nco * (k * k) * KC * NT * 16;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_conv2d_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wpacked, Cin,
+                     Cout, nchunk, nco, k * k, KC, NT);
+  return dv_launch_status();
+}
+
+extern "C" int dv_conv2d_f32(const float* in, const float* wpacked, const float* ch_scale, const float* ch_bias,
+                             const float* residual, float* out, int B, int Cin, int H, int W, int Cout, int k,
+                             int dilation, int act, dv_stream_t stream) {
+  DV_REQUIRE_PTR(in);
+  DV_REQUIRE_PTR(wpacked);
+  DV_REQUIRE_PTR(out);
+  DV_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, DV_ERR_SHAPE);
+  DV_REQUIRE(k == 1 || k == 3, DV_ERR_UNSUPPORTED);
+  DV_REQUIRE(k == 1 || (dilation >= 1 && dilation <= 16), DV_ERR_UNSUPPORTED);
+  DV_REQUIRE(act >= DV_ACT_NONE && act <= DV_ACT_LEAKY, DV_ERR_UNSUPPORTED);
+  DV_REQUIRE(dv_aligned16(wpacked), DV_ERR_ALIGN);
+  DV_REQUIRE((size_t)H * W * sizeof(float) <= 0xffffffffull, DV_ERR_SHAPE);
+  Conv2dArgs a;
+  a.in = in; a.wpk = wpacked; a.ch_scale = ch_scale; a.ch_bias = ch_bias; a.residual = residual; a.out = out;
+  a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.dil = k == 1 ? 0 : dilation; a.act = act;
+  a.vec_store = (W % 4 == 0) && dv_aligned16(out) && (!residual || dv_aligned16(residual));
+  a.fast_ok = a.vec_store && (size_t)Cout * H * W * sizeof(float) <= 0xffffffffull;
+  a.ntx = a.nty = a.nco = 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int NT = nt_of(Cout);
+  //                              KS NT KC DMAX BANDED
+  if (k == 1) {
+    if (NT == 2) return launch2d<G2<1, 2, 8, 0, false>>(a, s);
+    return launch2d<G2<1, 1, 8, 0, false>>(a, s);
+  }
+  if (dilation <= 4) {
+    if (NT == 2) return launch2d<G2<3, 2, 8, 4, false>>(a, s);
+    return launch2d<G2<3, 1, 8, 4, false>>(a, s);
+  }
+  if (NT == 2) return launch2d<G2<3, 2, 4, 16, true>>(a, s);
+  return launch2d<G2<3, 1, 4, 16, true>>(a, s);
+}

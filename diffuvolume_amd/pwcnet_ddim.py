@@ -9,8 +9,10 @@ HIP (libdiffuvolume_hip.so): the four group-wise-correlation and concat volumes 
 zero-fill flavour), dres0/dres1, ``hourglassup`` and, per DDIM step, the volume filter, the three
 Mish hourglasses, ``classif3``, the align_corners=True trilinear/softmax/regression tail with the
 uncertainty taken about the *refined* disparity, the two-hot re-encoding and the DDIM update.
-PyTorch (MIOpen / ATen): the 2-D feature CNN and the per-step 2-D refinement (bilinear feature
-upsampling, ``warp``, +-24 correlation, ``refinenet3``) -- SURVEY section 8(f) row 2, "next".
+Also HIP: the per-step 2-D refinement network ``refinenet3`` (dilated 3x3 convbn +
+Mish, BasicBlocks, 1x1 downsamples) on the 2-D implicit-GEMM kernel (csrc/conv2d.hip).
+PyTorch (MIOpen / ATen): the 2-D feature CNN and the refinement's input assembly (bilinear feature
+upsampling, ``warp``, +-24 correlation, concatenation).
 Differences from the ACV flavour: x_T = randn, 3 steps, fill = cumulative
 q_sample(asd), thresholds dif<1 & unc<1, ensemble [0.9,0,0,0.1], Mish activations.
 """
@@ -28,7 +30,7 @@ from . import _lib
 from .acv_ddim import ProbVolumeHandle, _bn_of, _plan_cb3, cosine_beta_schedule
 from .head import DynamicHead
 from .profiling import timed
-from .submodule import (ACT_MISH, ACT_NONE, Conv3dPlan, Deconv3dPlan, _dev_f32, build_concat_volume,
+from .submodule import (ACT_MISH, ACT_NONE, Conv2dPlan, Conv3dPlan, Deconv3dPlan, _dev_f32, build_concat_volume,
                         build_gwc_volume, check_split_overflow, upsample_softmax_regress)
 
 NoiseFn = Callable[[str, Tuple[int, ...], torch.dtype], torch.Tensor]
@@ -256,6 +258,42 @@ class _PairPlan:
         return self.b(self.a(x), residual=x if residual_self else None)
 
 
+def _plan_cb2(seq, act):
+    """convbn 2-D (Conv2d + BatchNorm2d, submodule.py:21-24) -> fused plan."""
+    conv, bn = seq[0], seq[1]
+    return Conv2dPlan(conv.weight, _bn_of(bn), dilation=conv.dilation[0], act=act, eps=bn.eps)
+
+
+class _Block2dPlan:
+    """BasicBlock (submodule.py:192-215): convbn+Mish, convbn, `out += x` (x through the 1x1 downsample when the
+    width changes); the add rides in the second convolution's epilogue, no activation after it."""
+
+    def __init__(self, blk: _Block2d):
+        self.conv1 = _plan_cb2(blk.conv1[0], ACT_MISH)
+        self.conv2 = _plan_cb2(blk.conv2, ACT_NONE)
+        self.down = None if blk.downsample is None else _plan_cb2(blk.downsample, ACT_NONE)
+
+    def __call__(self, x):
+        skip = x if self.down is None else self.down(x)
+        return self.conv2(self.conv1(x), residual=skip)
+
+
+class _RefinePlan:
+    """refinenet_version3.forward (pwcnet_ddim.py:292-306) on the 2-D implicit-GEMM kernel."""
+
+    def __init__(self, m: RefineNet):
+        self.head = [_plan_cb2(getattr(m, n)[0], ACT_MISH) for n in ("conv1", "conv2", "conv3", "conv4")]
+        self.blocks = [_Block2dPlan(b) for n in ("conv5", "conv6", "conv7") for b in getattr(m, n)]
+        self.conv8 = Conv2dPlan(m.conv8.weight, None, dilation=1, act=ACT_NONE)
+
+    def __call__(self, x, disp):
+        for p in self.head:
+            x = p(x)
+        for b in self.blocks:
+            x = b(x)
+        return self.conv8(x, residual=disp)          # disp + conv8(conv7)
+
+
 class _Plans:
     def __init__(self, m: "PWCNet_ddim"):
         self.dres0 = _PairPlan(m.dres0, ACT_MISH)
@@ -263,6 +301,7 @@ class _Plans:
         self.combine1 = _HourglassUpPlan(m.combine1)
         self.dres2, self.dres3, self.dres4 = (_HourglassPlan(h) for h in (m.dres2, m.dres3, m.dres4))
         self.classif3 = _PairPlan(m.classif3, ACT_NONE)
+        self.refinenet3 = _RefinePlan(m.refinenet3)
         ac = m.alphas_cumprod.detach().double().cpu()
         self.alphas_cumprod = ac
         self.sqrt_ac, self.sqrt_1mac = torch.sqrt(ac), torch.sqrt(1.0 - ac)
@@ -420,7 +459,7 @@ class PWCNet_ddim(nn.Module):
         frw = warp(fr, p3)
         cv = groupwise_corr_pm(fl, frw, 24)
         comb = torch.cat((fl - frw, fl, self.dispupsample(p3), p3, cv), dim=1)
-        return self.refinenet3(comb, p3).squeeze(1)
+        return self.prepare().refinenet3(comb.contiguous(), p3.contiguous()).squeeze(1)
 
     def _uncertainty_about(self, cost, disp):
         """sum_k |disp - k| * softmax(upsampled cost)_k with ``disp`` = the refined disparity (:548-552)."""

@@ -16,7 +16,7 @@ from . import _lib
 from .profiling import timed
 
 __all__ = ["build_gwc_volume", "build_concat_volume", "build_concat_attention_volume",
-           "disparity_regression", "upsample_softmax_regress", "Conv3dPlan", "Deconv3dPlan",
+           "disparity_regression", "upsample_softmax_regress", "Conv3dPlan", "Conv2dPlan", "Deconv3dPlan",
            "window_attention", "feature_gate", "softmax_regress", "ACT_NONE", "ACT_RELU", "ACT_MISH", "ACT_LEAKY"]
 
 ACT_NONE, ACT_RELU, ACT_MISH, ACT_LEAKY = 0, 1, 2, 3
@@ -272,6 +272,49 @@ class Conv3dPlan:
                                                        _lib.ptr(residual), out.data_ptr(), b, cin, d, h, w,
                                                        self.cout, self.k, self.stride, self.act,
                                                        _lib.stream_ptr()), "dv_conv3d_f32"))
+        return out
+
+
+class Conv2dPlan:
+    """Conv2d(k 3 or 1, stride 1, padding = dilation, bias=False) [+ BatchNorm2d eval] [+ residual] [+ activation]
+    on the 2-D implicit-GEMM kernel: `convbn` / `BasicBlock` of the KITTI12 refinement stack
+    (KITTI12/models/submodule.py:21-24, :192-215)."""
+
+    def __init__(self, weight: torch.Tensor, bn: Optional[Tuple[torch.Tensor, ...]] = None, dilation: int = 1,
+                 act: int = ACT_NONE, eps: float = 1e-5):
+        w = _dev_f32(weight.detach(), "weight")
+        self.cout, self.cin, k = w.shape[0], w.shape[1], w.shape[2]
+        if tuple(w.shape[2:]) != (k, k) or k not in (1, 3):
+            raise _lib.DiffuVolumeError(f"unsupported Conv2d kernel {tuple(w.shape[2:])}")
+        if k == 3 and not 1 <= dilation <= 16:
+            raise _lib.DiffuVolumeError("3x3 convolutions: dilation 1..16")
+        self.k, self.dilation, self.act = k, (dilation if k == 3 else 1), act
+        lib = _lib.load()
+        self.wpacked = torch.empty(lib.dv_conv2d_packed_floats(self.cin, self.cout, k, self.dilation),
+                                   dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            _lib.check(lib.dv_conv2d_pack_weights_f32(w.data_ptr(), self.wpacked.data_ptr(), self.cin, self.cout, k,
+                                                      self.dilation, _lib.stream_ptr()), "conv2d weight packing")
+        self.scale, self.shift = _fold_bn(bn, None, self.cout, w.device, eps)
+
+    def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        x = _dev_f32(x, "x")
+        b, cin, h, w = x.shape
+        if cin != self.cin:
+            raise RuntimeError(f"expected {self.cin} input channels, got {cin}")
+        out = torch.empty((b, self.cout, h, w), dtype=torch.float32, device=x.device)
+        if residual is not None:
+            residual = _dev_f32(residual, "residual")
+            if tuple(residual.shape) != tuple(out.shape):
+                raise RuntimeError("residual shape mismatch")
+        lib = _lib.load()
+        with torch.cuda.device(x.device):
+            nb = 4.0 * (x.numel() + out.numel() * (1 if residual is None else 2))
+            timed(f"conv2d_k{self.k}d{self.dilation}_co{self.cout}", 2.0 * out.numel() * cin * self.k ** 2, nb,
+                  lambda: _lib.check(lib.dv_conv2d_f32(x.data_ptr(), self.wpacked.data_ptr(), _lib.ptr(self.scale),
+                                                       _lib.ptr(self.shift), _lib.ptr(residual), out.data_ptr(), b, cin,
+                                                       h, w, self.cout, self.k, self.dilation, self.act,
+                                                       _lib.stream_ptr()), "dv_conv2d_f32"))
         return out
 
 

@@ -116,6 +116,18 @@ int dv_deconv3d_k4s2_f32(const float* in, const float* wpacked, const float* ch_
                          const float* ch_bias, const float* residual, float* out,
                          int B, int Cin, int D, int H, int W, int Cout, int act, dv_stream_t stream);
 
+/* ---- 2-D refinement stack (KITTI12 per-step disparity refinement) ------------------------------------
+ * convbn (KITTI12/models/submodule.py:21-24: Conv2d(k, stride 1, padding = dilation, bias=False) + BatchNorm2d)
+ * [+ Mish] and BasicBlock's `out += x` (:192-215), as used by refinenet_version3 (pwcnet_ddim.py:251-306):
+ *   out = act( conv2d(in, w; dilation) * ch_scale + ch_bias + residual ),  k = 3 (dilation 1..16) or 1.
+ * in [B,Cin,H,W], w [Cout,Cin,k,k], out / residual [B,Cout,H,W].  Weights are packed once per layer. */
+size_t dv_conv2d_packed_floats(int Cin, int Cout, int k, int dilation);
+int dv_conv2d_pack_weights_f32(const float* w, float* wpacked, int Cin, int Cout, int k, int dilation,
+                               dv_stream_t stream);
+int dv_conv2d_f32(const float* in, const float* wpacked, const float* ch_scale, const float* ch_bias,
+                  const float* residual, float* out, int B, int Cin, int H, int W, int Cout, int k,
+                  int dilation, int act, dv_stream_t stream);
+
 /* FeatureAtt.forward's broadcast product (KITTI15/core/submodule.py:234-239):
  * out[b,c,d,y,x] = sigmoid(logit[b,c,y,x]) * cv[b,c,d,y,x]; out may alias cv. */
 int dv_feature_gate_f32(const float* cv /*[B,C,D,H,W]*/, const float* logit /*[B,C,H,W]*/, float* out,

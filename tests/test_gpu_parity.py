@@ -498,3 +498,35 @@ def test_deconv_k4_oracle(cfg):
     plan = S.Deconv3dPlan(dev(w), tuple(dev(t) for t in bn), act=S.ACT_LEAKY)
     out = plan(dev(x))
     assert out.shape == y.shape and rel_err(out, y) < 1e-5
+
+
+@pytest.mark.parametrize("cfg", [
+    # cin, cout, k, dilation, (B, H, W), act, residual
+    (115, 128, 3, 1, (1, 16, 96), "mish", False),
+    (128, 128, 3, 2, (2, 11, 70), "mish", False),      # ragged rows and columns
+    (128, 128, 3, 4, (1, 24, 128), "mish", False),
+    (128, 96, 3, 8, (1, 24, 72), "mish", False),
+    (96, 96, 3, 8, (1, 19, 64), "none", True),
+    (64, 64, 3, 16, (1, 40, 130), "none", True),       # dilation larger than the tile, W % 4 != 0
+    (128, 96, 1, 1, (2, 9, 68), "none", False),
+    (32, 1, 3, 1, (1, 12, 80), "none", False),
+    (20, 24, 3, 3, (1, 10, 33), "relu", False),
+])
+def test_conv2d_oracle(cfg):
+    """convbn (+Mish, + BasicBlock residual) of the KITTI12 refinement stack (submodule.py:21-24, :192-215)."""
+    cin, cout, k, dil, dims, act, use_res = cfg
+    g = _gen(31, str(cfg))
+    x = torch.randn(dims[0], cin, dims[1], dims[2], generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (k * k * cin)) ** 0.5
+    bn = (torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1,
+          torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5)
+    res = torch.randn(dims[0], cout, dims[1], dims[2], generator=g) if use_res else None
+    y = torch.nn.functional.conv2d(x, w, None, 1, dil if k == 3 else 0, dil if k == 3 else 1)
+    y = torch.nn.functional.batch_norm(y, bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5)
+    if res is not None:
+        y = y + res
+    y = {"mish": lambda t: t * torch.tanh(torch.nn.functional.softplus(t)), "relu": torch.relu, "none": lambda t: t}[act](y)
+    plan = S.Conv2dPlan(dev(w), tuple(dev(t) for t in bn), dilation=dil,
+                        act={"mish": S.ACT_MISH, "relu": S.ACT_RELU, "none": S.ACT_NONE}[act])
+    out = plan(dev(x), residual=None if res is None else dev(res))
+    assert out.shape == y.shape and rel_err(out, y) < 1e-5

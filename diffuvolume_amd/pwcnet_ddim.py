@@ -31,7 +31,7 @@ from .acv_ddim import ProbVolumeHandle, _bn_of, _plan_cb3, cosine_beta_schedule
 from .head import DynamicHead
 from .profiling import timed
 from .submodule import (ACT_MISH, ACT_NONE, Conv2dPlan, Conv3dPlan, Deconv3dPlan, _dev_f32, build_concat_volume,
-                        build_gwc_volume, check_split_overflow, upsample_softmax_regress)
+                        build_gwc_volume, check_split_overflow, refine_inputs, upsample_softmax_regress)
 
 NoiseFn = Callable[[str, Tuple[int, ...], torch.dtype], torch.Tensor]
 
@@ -302,6 +302,10 @@ class _Plans:
         self.dres2, self.dres3, self.dres4 = (_HourglassPlan(h) for h in (m.dres2, m.dres3, m.dres4))
         self.classif3 = _PairPlan(m.classif3, ACT_NONE)
         self.refinenet3 = _RefinePlan(m.refinenet3)
+        conv, bn = m.dispupsample[0][0], m.dispupsample[0][1]          # 1x1 conv (1 -> 32) + BN folded to a*d + b
+        g = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float()
+        self.du_a = (conv.weight.detach().float().reshape(-1) * g).contiguous()
+        self.du_b = (bn.bias.detach().float() - bn.running_mean.detach().float() * g).contiguous()
         ac = m.alphas_cumprod.detach().double().cpu()
         self.alphas_cumprod = ac
         self.sqrt_ac, self.sqrt_1mac = torch.sqrt(ac), torch.sqrt(1.0 - ac)
@@ -450,16 +454,16 @@ class PWCNet_ddim(nn.Module):
         return p.classif3(p.dres4(p.dres3(p.dres2(volume, in_scale=n01f))))
 
     def _refine(self, pred3, features_left, features_right):
-        """pwcnet_ddim.py:486-502 (2-D, PyTorch): warp the right refinement feature by pred3, +-24
-        correlation, refinenet3 -> disp_finetune [B,H,W]."""
+        """pwcnet_ddim.py:486-502: warp the right refinement feature by pred3, +-24 correlation, concat
+        (one HIP kernel), refinenet3 (2-D implicit-GEMM kernel) -> disp_finetune [B,H,W].  The module-level
+        ``warp`` / ``groupwise_corr_pm`` are the PyTorch statement of the same input assembly."""
         hh, ww = pred3.shape[-2:]
         p3 = pred3.unsqueeze(1)
         fl = F.interpolate(features_left["finetune_feature"], [hh, ww], mode="bilinear", align_corners=True)
         fr = F.interpolate(features_right["finetune_feature"], [hh, ww], mode="bilinear", align_corners=True)
-        frw = warp(fr, p3)
-        cv = groupwise_corr_pm(fl, frw, 24)
-        comb = torch.cat((fl - frw, fl, self.dispupsample(p3), p3, cv), dim=1)
-        return self.prepare().refinenet3(comb.contiguous(), p3.contiguous()).squeeze(1)
+        plans = self.prepare()
+        comb = refine_inputs(fl, fr, p3, plans.du_a, plans.du_b, 24)      # warp, +-24 correlation, concat
+        return plans.refinenet3(comb, p3.contiguous()).squeeze(1)
 
     def _uncertainty_about(self, cost, disp):
         """sum_k |disp - k| * softmax(upsampled cost)_k with ``disp`` = the refined disparity (:548-552)."""

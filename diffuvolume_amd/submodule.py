@@ -17,7 +17,7 @@ from .profiling import timed
 
 __all__ = ["build_gwc_volume", "build_concat_volume", "build_concat_attention_volume",
            "disparity_regression", "upsample_softmax_regress", "Conv3dPlan", "Conv2dPlan", "Deconv3dPlan",
-           "window_attention", "feature_gate", "softmax_regress", "ACT_NONE", "ACT_RELU", "ACT_MISH", "ACT_LEAKY"]
+           "window_attention", "feature_gate", "softmax_regress", "refine_inputs", "ACT_NONE", "ACT_RELU", "ACT_MISH", "ACT_LEAKY"]
 
 ACT_NONE, ACT_RELU, ACT_MISH, ACT_LEAKY = 0, 1, 2, 3
 
@@ -388,6 +388,27 @@ def feature_gate(cv: torch.Tensor, logit: torch.Tensor, inplace: bool = False) -
         timed("feature_gate", float(cv.numel()), 8.0 * cv.numel(),
               lambda: _lib.check(lib.dv_feature_gate_f32(cv.data_ptr(), logit.data_ptr(), out.data_ptr(), b, c, d, h, w,
                                                          _lib.stream_ptr()), "dv_feature_gate_f32"))
+    return out
+
+
+def refine_inputs(left: torch.Tensor, right: torch.Tensor, disp: torch.Tensor, du_a: torch.Tensor,
+                  du_b: torch.Tensor, maxshift: int = 24) -> torch.Tensor:
+    """cat(left - warp(right, disp), left, Mish(du_a*disp + du_b), disp, corr(left, warp(right, disp), +-24)):
+    the refinement network's input (KITTI12/models/pwcnet_ddim.py:486-502) in one kernel.
+    left/right [B,C,H,W], disp [B,1,H,W] or [B,H,W] -> [B, 3C+1+49, H, W]."""
+    left, right = _dev_f32(left, "left"), _dev_f32(right, "right")
+    disp = _dev_f32(disp, "disp")
+    b, c, h, w = left.shape
+    if tuple(right.shape) != (b, c, h, w) or disp.numel() != b * h * w:
+        raise RuntimeError("left / right / disp shapes do not match")
+    du_a, du_b = _dev_f32(du_a, "du_a"), _dev_f32(du_b, "du_b")
+    out = torch.empty((b, 3 * c + 1 + 2 * maxshift + 1, h, w), dtype=torch.float32, device=left.device)
+    lib = _lib.load()
+    with torch.cuda.device(left.device):
+        timed("refine_inputs", 2.0 * b * h * w * c * (2 * maxshift + 1), 4.0 * (2 * left.numel() + out.numel()),
+              lambda: _lib.check(lib.dv_refine_inputs_f32(left.data_ptr(), right.data_ptr(), disp.data_ptr(),
+                                                          du_a.data_ptr(), du_b.data_ptr(), out.data_ptr(), b, c, h, w,
+                                                          maxshift, _lib.stream_ptr()), "dv_refine_inputs_f32"))
     return out
 
 

@@ -128,6 +128,16 @@ int dv_conv2d_f32(const float* in, const float* wpacked, const float* ch_scale, 
                   const float* residual, float* out, int B, int Cin, int H, int W, int Cout, int k,
                   int dilation, int act, dv_stream_t stream);
 
+/* Input assembly of that refinement (KITTI12/models/pwcnet_ddim.py:486-502), fused:
+ *   frw = warp(right, disp)  (models/submodule.py:137-176, incl. its align_corners mismatch and >= 0.999 mask),
+ *   cv  = build_corrleation_volume(left, frw, maxshift, 1)  (:121-135, incl. its negative-shift slicing),
+ *   out = cat(left - frw, left, Mish(du_a * disp + du_b), disp, cv)   [B, 3C + 1 + 2*maxshift + 1, H, W].
+ * left/right [B,C,H,W] (C <= 32), disp [B,H,W]; du_a/du_b [C] = `dispupsample` (1x1 conv + BN) folded;
+ * maxshift must be 24. */
+int dv_refine_inputs_f32(const float* left, const float* right, const float* disp, const float* du_a,
+                         const float* du_b, float* out, int B, int C, int H, int W, int maxshift,
+                         dv_stream_t stream);
+
 /* FeatureAtt.forward's broadcast product (KITTI15/core/submodule.py:234-239):
  * out[b,c,d,y,x] = sigmoid(logit[b,c,y,x]) * cv[b,c,d,y,x]; out may alias cv. */
 int dv_feature_gate_f32(const float* cv /*[B,C,D,H,W]*/, const float* logit /*[B,C,H,W]*/, float* out,

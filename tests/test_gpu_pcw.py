@@ -119,3 +119,24 @@ def test_forward_golden():
     d = (out[0].cpu() - g["pred"]).abs()
     assert float(d.median()) < 2e-4, float(d.median())
     assert float(d.mean()) < 2e-2, float(d.mean())
+
+
+@pytest.mark.parametrize("shape", [(1, 32, 12, 160), (2, 32, 7, 130), (1, 20, 5, 40)])
+def test_refine_inputs_vs_torch_composition(shape):
+    """The fused warp + +-24 correlation + concat kernel against the PyTorch statement of pwcnet_ddim.py:486-502
+    (warp / build_corrleation_volume restated in diffuvolume_amd.pwcnet_ddim and pinned by the oracle tests),
+    including disparities that push samples off both image edges and the wrap-around negative shifts."""
+    from diffuvolume_amd.pwcnet_ddim import groupwise_corr_pm, warp
+    from diffuvolume_amd.submodule import refine_inputs
+    b, c, h, w = shape
+    g = _gen(77, str(shape))
+    fl, fr = torch.randn(b, c, h, w, generator=g), torch.randn(b, c, h, w, generator=g)
+    p3 = torch.rand(b, 1, h, w, generator=g) * 60 - 6
+    du_a, du_b = torch.randn(c, generator=g) * 0.1, torch.randn(c, generator=g) * 0.1
+    frw = warp(fr, p3)
+    aff = du_a.view(1, c, 1, 1) * p3 + du_b.view(1, c, 1, 1)
+    ref = torch.cat((fl - frw, fl, aff * torch.tanh(torch.nn.functional.softplus(aff)), p3,
+                     groupwise_corr_pm(fl, frw, 24)), dim=1)
+    out = refine_inputs(dev(fl), dev(fr), dev(p3), dev(du_a), dev(du_b), 24)
+    assert out.shape == ref.shape
+    torch.testing.assert_close(out.cpu(), ref, atol=2e-5, rtol=1e-5)

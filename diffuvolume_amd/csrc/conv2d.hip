@@ -24,15 +24,17 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int TH = 8, MTX = 4, TW = MTX * 16, RPW = 2, MT = RPW * MTX;
+constexpr int MTX = 4, TW = MTX * 16;
 
 __host__ __device__ constexpr int plane_pad(int n) {   // smallest p > n with p % 32 == 16 (bank rule + a spare slot)
   return (n + 1) + ((16 - (n + 1) % 32) + 32) % 32;
 }
 
-template <int KS_, int NT_, int KC_, int DMAX_, bool BANDED_>
+template <int KS_, int NT_, int KC_, int DMAX_, bool BANDED_, int RPW_, int WPS_ = 2>
 struct G2 {
+  static constexpr int WPS = WPS_;     // blocks per CU the register budget is set for
   static constexpr int KS = KS_, NT = NT_, KC = KC_, DMAX = DMAX_;
+  static constexpr int RPW = RPW_, TH = 4 * RPW_, MT = RPW_ * MTX;     // 4 waves x RPW rows
   static constexpr bool BANDED = BANDED_;
   static constexpr int T = KS * KS, NKS = KC / 4, COUT = NT * 16;
   static constexpr int BV = NKS * NT;                 // B floats per lane and tap: [ks][n]
@@ -43,7 +45,7 @@ struct G2 {
   static constexpr int PMAX = plane_pad(RMAX * CMAX);
   static constexpr int IN_FLOATS = KC * PMAX, W_FLOATS = T * KC * COUT;
   static_assert(BV == 1 || BV == 2 || BV % 4 == 0, "B vector width");
-  static_assert((IN_FLOATS + W_FLOATS) * 4 <= 80 * 1024, "two blocks per CU");
+  static_assert((IN_FLOATS + W_FLOATS) * 4 * WPS <= 160 * 1024, "WPS blocks per CU");
 };
 
 struct Conv2dArgs {
@@ -60,8 +62,9 @@ struct Conv2dArgs {
 };
 
 template <class G>
-__global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(Conv2dArgs a) {
+__global__ __launch_bounds__(256, G::WPS) void conv2d_mfma_kernel(Conv2dArgs a) {
   constexpr int KS = G::KS, NT = G::NT, KC = G::KC, NKS = G::NKS, BV = G::BV, VW = G::VW, Q = G::Q, T = G::T;
+  constexpr int TH = G::TH, RPW = G::RPW, MT = G::MT;
   __shared__ __attribute__((aligned(16))) float smem[G::IN_FLOATS + G::W_FLOATS];
   float* in_s = smem;
   float* w_s = smem + G::IN_FLOATS;
@@ -93,8 +96,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(Conv2dArgs a) {
   constexpr int NS = (G::RMAX * G::CMAX + 255) / 256;
   constexpr int NQ = G::W_FLOATS / 4, NWQ = (NQ + 255) / 256;
   unsigned sob[NS];
-  bool sok[NS];
-  int wslot[NS];
+  unsigned okmask = 0;       // bit i: position i of this thread lies inside the image
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
     const int r = tid + 256 * i;
@@ -103,8 +105,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(Conv2dArgs a) {
     const int gx = x0 - (KS / 2) * d + col;
     const bool ok = r < R * C && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
     sob[i] = ok ? (unsigned)(gy * a.W + gx) * 4u : 0u;
-    sok[i] = ok;
-    wslot[i] = r < R * C ? r : P - 1;     // threads past the brick write the plane's spare slot
+    okmask |= ok ? (1u << i) : 0u;
   }
   float vin[KC][NS];
   f32x4 vw[NWQ];
@@ -129,7 +130,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(Conv2dArgs a) {
     for (int cl = 0; cl < KC; ++cl) {
       const bool cok = (c * KC + cl) < a.Cin;
 #pragma unroll
-      for (int i = 0; i < NS; ++i) in_s[cl * P + wslot[i]] = (cok && sok[i]) ? vin[cl][i] : 0.f;
+      for (int i = 0; i < NS; ++i) {
+        const int r = tid + 256 * i;      // threads past the brick write the plane's spare slot
+        in_s[cl * P + (r < R * C ? r : P - 1)] = (cok && ((okmask >> i) & 1u)) ? vin[cl][i] : 0.f;
+      }
     }
 #pragma unroll
     for (int q = 0; q < NWQ; ++q) {
@@ -141,13 +145,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(Conv2dArgs a) {
   // step s = (tap, ks): 8 A fragments (2 rows x 4 M-tiles) + the tap's B vector
   const float* abase = in_s + kq * P + (wave * RPW) * C + j;
   const float* bbase = w_s + lane * VW;
-  auto load_a = [&](float (&av)[MT], int tap, int ks) __attribute__((always_inline)) {
+  // (dq, Cq, Pq) are per-chunk opaque copies of (d, C, P): without them the compiler hoists the 9*NKS*RPW
+  // tap addresses out of the channel loop and parks them in ~50 VGPRs; recomputing them is a scalar add each.
+  auto load_a = [&](float (&av)[MT], int tap, int ks, int dq, int Cq, int Pq) __attribute__((always_inline)) {
     const int ky = tap / KS, kx = tap - ky * KS;
-    const int off = (G::BANDED ? ky * TH : ky * d) * C + kx * d + ks * 4 * P;   // wave-uniform
+    const int off = (G::BANDED ? ky * TH : ky * dq) * Cq + kx * dq + ks * 4 * Pq;   // wave-uniform
 #pragma unroll
     for (int r = 0; r < RPW; ++r)
 #pragma unroll
-      for (int xt = 0; xt < MTX; ++xt) av[r * MTX + xt] = abase[off + r * C + xt * 16];
+      for (int xt = 0; xt < MTX; ++xt) av[r * MTX + xt] = abase[off + r * Cq + xt * 16];
   };
   auto load_b = [&](float (&bv)[BV], int tap) __attribute__((always_inline)) {
 #pragma unroll
@@ -175,13 +181,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(Conv2dArgs a) {
     if (c + 1 < nchunk) fetch(c + 1);
     float av[2][MT];
     float bv[2][BV];
-    load_a(av[0], 0, 0);
+    int dq = d, Cq = C, Pq = P;
+    asm volatile("" : "+s"(dq), "+s"(Cq), "+s"(Pq));
+    load_a(av[0], 0, 0, dq, Cq, Pq);
     load_b(bv[0], 0);
 #pragma unroll
     for (int s = 0; s < T * NKS; ++s) {
       const int tap = s / NKS, ks = s - tap * NKS;
       if (s + 1 < T * NKS) {
-        load_a(av[(s + 1) & 1], (s + 1) / NKS, (s + 1) % NKS);
+        load_a(av[(s + 1) & 1], (s + 1) / NKS, (s + 1) % NKS, dq, Cq, Pq);
         if ((s + 1) % NKS == 0) load_b(bv[((s + 1) / NKS) & 1], (s + 1) / NKS);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -293,12 +301,12 @@ inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 // geometry choice: N tiles per block by Cout, chunk depth by what fits two blocks per CU
 // (NT = 4 would halve the staging traffic of the wide layers but needs 128 accumulator registers: it spills)
 inline int nt_of(int Cout) { return Cout > 16 ? 2 : 1; }
-inline int kc_of(int k, int dil) { return (k == 3 && dil > 4) ? 4 : 8; }
+inline int kc_of(int k, int /*dil*/) { return k == 3 ? 4 : 8; }
 
 template <class G>
 int launch2d(Conv2dArgs a, hipStream_t s) {
   a.ntx = (a.W + TW - 1) / TW;
-  a.nty = (a.H + TH - 1) / TH;
+  a.nty = (a.H + G::TH - 1) / G::TH;
   a.nco = pad_to(a.Cout, G::COUT) / G::COUT;
   const long long blocks = (long long)a.B * a.nco * a.nty * a.ntx;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return DV_ERR_SHAPE;
@@ -349,15 +357,18 @@ extern "C" int dv_conv2d_f32(const float* in, const float* wpacked, const float*
   a.ntx = a.nty = a.nco = 0;
   hipStream_t s = (hipStream_t)stream;
   const int NT = nt_of(Cout);
-  //                              KS NT KC DMAX BANDED
+  //                              KS NT KC DMAX BANDED RPW [WPS]
   if (k == 1) {
-    if (NT == 2) return launch2d<G2<1, 2, 8, 0, false>>(a, s);
-    return launch2d<G2<1, 1, 8, 0, false>>(a, s);
+    if (NT == 2) return launch2d<G2<1, 2, 8, 0, false, 2>>(a, s);
+    return launch2d<G2<1, 1, 8, 0, false, 2>>(a, s);
   }
+  // 3x3: chunks of 4 channels and <= 170 registers, so three blocks share a CU (measured 109 vs 100 TFLOP/s for
+  // 8-channel chunks at two blocks per CU: a third resident wave per SIMD hides the staging phases better than
+  // longer MFMA runs do)
   if (dilation <= 4) {
-    if (NT == 2) return launch2d<G2<3, 2, 8, 4, false>>(a, s);
-    return launch2d<G2<3, 1, 8, 4, false>>(a, s);
+    if (NT == 2) return launch2d<G2<3, 2, 4, 4, false, 2, 3>>(a, s);
+    return launch2d<G2<3, 1, 4, 4, false, 2, 3>>(a, s);
   }
-  if (NT == 2) return launch2d<G2<3, 2, 4, 16, true>>(a, s);
-  return launch2d<G2<3, 1, 4, 16, true>>(a, s);
+  if (NT == 2) return launch2d<G2<3, 2, 4, 16, true, 2, 2>>(a, s);   // 9 staged positions per thread: spills at 170 registers
+  return launch2d<G2<3, 1, 4, 16, true, 2, 3>>(a, s);
 }

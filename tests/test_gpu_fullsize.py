@@ -1,0 +1,137 @@
+"""Config-2 sizes (BASELINE.json: 960x512 frames -> 48 x 128 x 240 volumes, batch 8) checked through properties
+that do not need the CPU oracle to finish: exact structure of the builders, linearity / shift equivariance of the
+aggregation layers, agreement with PyTorch's own fp32 ops on the GPU for single layers, softmax shift invariance of
+the regression tail, run-to-run determinism and batch-shard invariance of the whole 5-step hot path (the latter is
+what the multi-GPU sharding relies on).  The full-size pair-0 comparison with the CPU oracle itself is part of
+bench.py (`parity_vs_oracle_step1`)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import diffuvolume_amd as dv
+from diffuvolume_amd import submodule as S
+from diffuvolume_amd.synth import NoiseTape, _gen, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+B, D, H, W = 8, 48, 128, 240
+
+
+def rnd(key, *shape):
+    return torch.randn(*shape, generator=_gen(41, key)).to(DEV)
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp(min=1e-30))
+
+
+def test_gwc_structure_and_linearity():
+    fl, fr = rnd("fl", B, 320, H, W), rnd("fr", B, 320, H, W)
+    vol = dv.build_gwc_volume(fl, fr, D, 40)
+    assert vol.shape == (B, 40, D, H, W)
+    for d in (1, 7, 47):                                     # zero wedge x < d
+        assert float(vol[:, :, d, :, :d].abs().max()) == 0.0
+    ref0 = (fl * fr).view(B, 40, 8, H, W).mean(2)            # d = 0 slice = plain group-wise correlation
+    assert rel(vol[:, :, 0], ref0) < 1e-6
+    d = 13                                                   # one shifted slice against the definition
+    refd = (fl[..., d:] * fr[..., :-d]).view(B, 40, 8, H, W - d).mean(2)
+    assert rel(vol[:, :, d, :, d:], refd) < 1e-6
+    vol2 = dv.build_gwc_volume(fl * 2.0, fr, D, 40)          # scaling by a power of two is exact
+    assert torch.equal(vol2, vol * 2.0)
+
+
+def test_concat_is_an_exact_copy():
+    cl, cr = rnd("cl", B, 32, H, W), rnd("cr", B, 32, H, W)
+    vol = dv.build_concat_volume(cl, cr, D)
+    assert vol.shape == (B, 64, D, H, W)
+    for d in (0, 5, 47):
+        assert torch.equal(vol[:, :32, d], cl)                       # SceneFlow flavour: left half for every x
+        assert torch.equal(vol[:, 32:, d, :, d:], cr[..., :W - d])
+        if d:
+            assert float(vol[:, 32:, d, :, :d].abs().max()) == 0.0
+    k12 = dv.build_concat_volume(cl, cr, D, zero_left=True)          # KITTI12 flavour: both halves zero for x < d
+    assert torch.equal(k12[:, :32, 5, :, 5:], cl[..., 5:]) and float(k12[:, :, 5, :, :5].abs().max()) == 0.0
+    att = rnd("att", B, 1, D, H, W)
+    av = dv.build_concat_attention_volume(cl, cr, att, D)
+    p = torch.softmax(att, dim=2)
+    assert rel(av[:, :, 9], p[:, :, 9] * vol[:, :, 9]) < 1e-6
+
+
+def test_conv3d_linearity_shift_and_torch_reference():
+    w = rnd("w", 32, 32, 3, 3, 3) * 0.05
+    plan = S.Conv3dPlan(w, None, stride=1, act=S.ACT_NONE, precision="f32")
+    x1, x2 = rnd("x1", B, 32, D, H, W), rnd("x2", B, 32, D, H, W)
+    y1, y2, y12 = plan(x1), plan(x2), plan(x1 + x2)
+    assert rel(y12, y1 + y2) < 2e-5                          # linear up to fp32 re-association
+    xs = torch.roll(x1, shifts=(1, 1, 1), dims=(2, 3, 4))    # translation equivariance away from the borders
+    ys = plan(xs)
+    assert rel(ys[:, :, 2:-2, 2:-2, 2:-2], torch.roll(y1, shifts=(1, 1, 1), dims=(2, 3, 4))[:, :, 2:-2, 2:-2, 2:-2]) < 1e-6
+    ref = F.conv3d(x1[:1], w, None, 1, 1)                    # PyTorch's own fp32 convolution, one full-size item
+    assert rel(y1[:1], ref) < 1e-5
+    del y2, y12, ys
+    bn = tuple(rnd(k, 32).abs() + 0.5 if k in ("g", "v") else rnd(k, 32) * 0.1 for k in ("g", "b", "m", "v"))
+    res = rnd("res", 1, 32, D, H, W)
+    yb = S.Conv3dPlan(w, bn, stride=1, act=S.ACT_RELU, precision="f32")(x1[:1], residual=res)
+    refb = torch.relu(F.batch_norm(ref, bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5) + res)
+    assert rel(yb, refb) < 1e-5
+
+
+def test_strided_and_transposed_conv_torch_reference():
+    w2 = rnd("w2", 64, 32, 3, 3, 3) * 0.05
+    x = rnd("xs2", 1, 32, D, H, W)
+    assert rel(S.Conv3dPlan(w2, None, stride=2, act=S.ACT_NONE, precision="f32")(x), F.conv3d(x, w2, None, 2, 1)) < 1e-5
+    wt = rnd("wt", 64, 32, 3, 3, 3) * 0.05
+    xt = rnd("xt", 1, 64, D // 2, H // 2, W // 2)
+    skip = rnd("skip", 1, 32, D, H, W)
+    y = S.Deconv3dPlan(wt, None, act=S.ACT_RELU)(xt, residual=skip)
+    assert rel(y, torch.relu(F.conv_transpose3d(xt, wt, None, 2, 1, 1) + skip)) < 1e-5
+
+
+def test_regression_tail_properties():
+    cost = rnd("cost", B, 1, D, H, W) * 3
+    disp, unc = S.upsample_softmax_regress(cost)
+    assert disp.shape == (B, 4 * H, 4 * W) and float(disp.min()) >= 0.0 and float(disp.max()) <= 191.0
+    assert float(unc.min()) >= 0.0
+    disp2, _ = S.upsample_softmax_regress(cost + 3.0)        # softmax is shift invariant
+    assert float((disp2 - disp).abs().max()) < 2e-3
+    up = F.interpolate(cost[:1], scale_factor=4, mode="trilinear", align_corners=False).squeeze(1)
+    p = torch.softmax(up, dim=1)
+    k = torch.arange(192, device=DEV, dtype=torch.float32).view(1, 192, 1, 1)
+    ref = (p * k).sum(1)
+    assert float((disp[:1] - ref).abs().max()) < 2e-3
+    assert float((unc[:1] - ((ref.unsqueeze(1) - k).abs() * p).sum(1)).abs().max()) < 5e-3
+
+
+@pytest.fixture(scope="module")
+def hot():
+    model = dv.ACVNet_DDIM(192, False, False)
+    model.load_state_dict(synth_state_dict(model.state_dict(), seed=1, logit_gain=8.0), strict=True)
+    model = model.to(DEV).eval()
+    x = dict(cl=rnd("hcl", B, 32, H, W), cr=rnd("hcr", B, 32, H, W), att=rnd("hatt", B, 1, D, H, W) * 2,
+             used=(torch.rand(B, 4 * H, 4 * W, generator=_gen(41, "used")) * 150 + 5).to(DEV))
+    x["dq"] = F.interpolate(x["used"].unsqueeze(1), size=(H, W), mode="bilinear") / 4
+    return model, x
+
+
+def run_hot(model, x, lo, hi, seed=5):
+    tape = NoiseTape(seed)
+
+    def draw(kind, shape, dtype):                            # draws of the full batch, sliced to this shard
+        return tape(kind, (B,) + tuple(shape[1:]), dtype)[lo:hi]
+
+    with torch.no_grad():
+        vol = dv.build_concat_attention_volume(x["cl"][lo:hi], x["cr"][lo:hi], x["att"][lo:hi], D)
+        x_t = model.encode_disparity(x["dq"][lo:hi])
+        final, stack = model.ddim_sample(vol, x["used"][lo:hi], x_t, noise=draw)
+    return final, stack
+
+
+def test_hot_path_determinism_and_shard_invariance(hot):
+    model, x = hot
+    full, stack = run_hot(model, x, 0, B)
+    again, _ = run_hot(model, x, 0, B)
+    assert torch.equal(full, again)                          # same inputs, same noise -> same bits
+    assert bool(torch.isfinite(full).all()) and stack.shape[0] == 6
+    for lo, hi in ((0, 4), (4, 8), (5, 6)):                  # what rank r of an N-GPU run computes for its slice
+        part, _ = run_hot(model, x, lo, hi)
+        assert torch.equal(part, full[lo:hi]), (lo, hi)

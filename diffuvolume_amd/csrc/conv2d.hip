@@ -24,15 +24,15 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int MTX = 4, TW = MTX * 16;
 
 __host__ __device__ constexpr int plane_pad(int n) {   // smallest p > n with p % 32 == 16 (bank rule + a spare slot)
   return (n + 1) + ((16 - (n + 1) % 32) + 32) % 32;
 }
 
-template <int KS_, int NT_, int KC_, int DMAX_, bool BANDED_, int RPW_, int WPS_ = 2>
+template <int KS_, int NT_, int KC_, int DMAX_, bool BANDED_, int RPW_, int WPS_ = 2, int MTX_ = 4>
 struct G2 {
   static constexpr int WPS = WPS_;     // blocks per CU the register budget is set for
+  static constexpr int MTX = MTX_, TW = MTX_ * 16;     // M tiles (16 columns each) per row
   static constexpr int KS = KS_, NT = NT_, KC = KC_, DMAX = DMAX_;
   static constexpr int RPW = RPW_, TH = 4 * RPW_, MT = RPW_ * MTX;     // 4 waves x RPW rows
   static constexpr bool BANDED = BANDED_;
@@ -54,6 +54,9 @@ struct Conv2dArgs {
   const float* ch_scale;  // [Cout] or null
   const float* ch_bias;   // [Cout] or null
   const float* residual;  // [B,Cout,H,W] or null
+  const float* mul;       // [B,Cout,H,W] or null: v *= mul after the activation
+  const float* blend_z;   // [B,Cout,H,W] or null: v = blend_h + blend_z * (v - blend_h)
+  const float* blend_h;
   float* out;             // [B,Cout,H,W]
   int B, Cin, H, W, Cout;
   int dil;                // dilation (= padding); 0 for 1x1
@@ -64,7 +67,7 @@ struct Conv2dArgs {
 template <class G>
 __global__ __launch_bounds__(256, G::WPS) void conv2d_mfma_kernel(Conv2dArgs a) {
   constexpr int KS = G::KS, NT = G::NT, KC = G::KC, NKS = G::NKS, BV = G::BV, VW = G::VW, Q = G::Q, T = G::T;
-  constexpr int TH = G::TH, RPW = G::RPW, MT = G::MT;
+  constexpr int TH = G::TH, RPW = G::RPW, MT = G::MT, MTX = G::MTX, TW = G::TW;
   __shared__ __attribute__((aligned(16))) float smem[G::IN_FLOATS + G::W_FLOATS];
   float* in_s = smem;
   float* w_s = smem + G::IN_FLOATS;
@@ -205,9 +208,12 @@ __global__ __launch_bounds__(256, G::WPS) void conv2d_mfma_kernel(Conv2dArgs a) 
   // ---- epilogue: BN scale/bias, residual, activation; lane = 4 x of one channel ----
   const bool fast = a.fast_ok && co0 + G::COUT <= a.Cout && x0 + TW <= a.W && y0 + TH <= a.H;
   const float slope = a.act == DV_ACT_RELU ? 0.f : (a.act == DV_ACT_LEAKY ? 0.01f : 1.f);
-  auto epilogue_fast = [&](auto mishc, auto resc) __attribute__((always_inline)) {
-    constexpr bool MISH = decltype(mishc)::value;
+  // GEN: activations that need a transcendental (Mish, sigmoid, tanh), chosen per element by a uniform switch;
+  // GATED: the ConvGRU operands (mul / blend) are present
+  auto epilogue_fast = [&](auto genc, auto resc, auto gatedc) __attribute__((always_inline)) {
+    constexpr bool GEN = decltype(genc)::value;
     constexpr bool RES = decltype(resc)::value;
+    constexpr bool GATED = decltype(gatedc)::value;
     unsigned loff[NT];
     float sc[NT], bi[NT];
 #pragma unroll
@@ -235,19 +241,33 @@ __global__ __launch_bounds__(256, G::WPS) void conv2d_mfma_kernel(Conv2dArgs a) 
           f32x4 v = acc[r * MTX + xt][n] * sc[n] + bi[n];
           if (RES) v += rv[xt];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = MISH ? dv_act(v[e], DV_ACT_MISH) : fmaxf(v[e], v[e] * slope);
+          for (int e = 0; e < 4; ++e) v[e] = GEN ? dv_act(v[e], a.act) : fmaxf(v[e], v[e] * slope);
+          if (GATED) {
+            const size_t go = rowo * sizeof(float) + loff[n] + xt * 64;
+            if (a.mul) v *= *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.mul) + go);
+            if (a.blend_z) {
+              const f32x4 z = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.blend_z) + go);
+              const f32x4 h = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.blend_h) + go);
+              v = h + z * (v - h);
+            }
+          }
           *reinterpret_cast<f32x4*>(orow + loff[n] + xt * 64) = v;
         }
       }
     }
   };
   if (fast) {
-    if (a.act == DV_ACT_MISH) {
-      if (a.residual) epilogue_fast(std::true_type{}, std::true_type{});
-      else epilogue_fast(std::true_type{}, std::false_type{});
+    const bool gen = a.act == DV_ACT_MISH || a.act == DV_ACT_SIGMOID || a.act == DV_ACT_TANH;
+    auto go = [&](auto genc, auto resc) __attribute__((always_inline)) {
+      if (a.mul || a.blend_z) epilogue_fast(genc, resc, std::true_type{});
+      else epilogue_fast(genc, resc, std::false_type{});
+    };
+    if (gen) {
+      if (a.residual) go(std::true_type{}, std::true_type{});
+      else go(std::true_type{}, std::false_type{});
     } else {
-      if (a.residual) epilogue_fast(std::false_type{}, std::true_type{});
-      else epilogue_fast(std::false_type{}, std::false_type{});
+      if (a.residual) go(std::false_type{}, std::true_type{});
+      else go(std::false_type{}, std::false_type{});
     }
     return;
   }
@@ -268,7 +288,10 @@ __global__ __launch_bounds__(256, G::WPS) void conv2d_mfma_kernel(Conv2dArgs a) 
         if (xo + e < a.W) {
           float u = fmaf(acc[m][n][e], sc, bi);
           if (a.residual) u += a.residual[o + e];
-          a.out[o + e] = dv_act(u, a.act);
+          u = dv_act(u, a.act);
+          if (a.mul) u *= a.mul[o + e];
+          if (a.blend_z) u = a.blend_h[o + e] + a.blend_z[o + e] * (u - a.blend_h[o + e]);
+          a.out[o + e] = u;
         }
     }
   }
@@ -305,7 +328,7 @@ inline int kc_of(int k, int /*dil*/) { return k == 3 ? 4 : 8; }
 
 template <class G>
 int launch2d(Conv2dArgs a, hipStream_t s) {
-  a.ntx = (a.W + TW - 1) / TW;
+  a.ntx = (a.W + G::TW - 1) / G::TW;
   a.nty = (a.H + G::TH - 1) / G::TH;
   a.nco = pad_to(a.Cout, G::COUT) / G::COUT;
   const long long blocks = (long long)a.B * a.nco * a.nty * a.ntx;
@@ -337,22 +360,25 @@ extern "C" int dv_conv2d_pack_weights_f32(const float* w, float* wpacked, int Ci
   return dv_launch_status();
 }
 
-extern "C" int dv_conv2d_f32(const float* in, const float* wpacked, const float* ch_scale, const float* ch_bias,
-                             const float* residual, float* out, int B, int Cin, int H, int W, int Cout, int k,
-                             int dilation, int act, dv_stream_t stream) {
+static int conv2d_run(const float* in, const float* wpacked, const float* ch_scale, const float* ch_bias,
+                      const float* residual, const float* mul, const float* blend_z, const float* blend_h, float* out,
+                      int B, int Cin, int H, int W, int Cout, int k, int dilation, int act, dv_stream_t stream) {
   DV_REQUIRE_PTR(in);
   DV_REQUIRE_PTR(wpacked);
   DV_REQUIRE_PTR(out);
   DV_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, DV_ERR_SHAPE);
   DV_REQUIRE(k == 1 || k == 3, DV_ERR_UNSUPPORTED);
   DV_REQUIRE(k == 1 || (dilation >= 1 && dilation <= 16), DV_ERR_UNSUPPORTED);
-  DV_REQUIRE(act >= DV_ACT_NONE && act <= DV_ACT_LEAKY, DV_ERR_UNSUPPORTED);
+  DV_REQUIRE(act >= DV_ACT_NONE && act <= DV_ACT_TANH, DV_ERR_UNSUPPORTED);
+  DV_REQUIRE((blend_z == nullptr) == (blend_h == nullptr), DV_ERR_NULL);
   DV_REQUIRE(dv_aligned16(wpacked), DV_ERR_ALIGN);
   DV_REQUIRE((size_t)H * W * sizeof(float) <= 0xffffffffull, DV_ERR_SHAPE);
   Conv2dArgs a;
   a.in = in; a.wpk = wpacked; a.ch_scale = ch_scale; a.ch_bias = ch_bias; a.residual = residual; a.out = out;
+  a.mul = mul; a.blend_z = blend_z; a.blend_h = blend_h;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.dil = k == 1 ? 0 : dilation; a.act = act;
-  a.vec_store = (W % 4 == 0) && dv_aligned16(out) && (!residual || dv_aligned16(residual));
+  a.vec_store = (W % 4 == 0) && dv_aligned16(out) && (!residual || dv_aligned16(residual)) &&
+                (!mul || dv_aligned16(mul)) && (!blend_z || (dv_aligned16(blend_z) && dv_aligned16(blend_h)));
   a.fast_ok = a.vec_store && (size_t)Cout * H * W * sizeof(float) <= 0xffffffffull;
   a.ntx = a.nty = a.nco = 0;
   hipStream_t s = (hipStream_t)stream;
@@ -366,9 +392,32 @@ extern "C" int dv_conv2d_f32(const float* in, const float* wpacked, const float*
   // 8-channel chunks at two blocks per CU: a third resident wave per SIMD hides the staging phases better than
   // longer MFMA runs do)
   if (dilation <= 4) {
-    if (NT == 2) return launch2d<G2<3, 2, 4, 4, false, 2, 3>>(a, s);
+    if (NT == 2) {
+      // 64-column tiles unless 32-column ones use the chip's 768 block slots (3 per CU) clearly better: small
+      // images (IGEV's 1/4 .. 1/16 resolution GRUs) otherwise run one and a bit rounds of blocks
+      const long long rows = (long long)B * ((H + 7) / 8) * ((Cout + 31) / 32);
+      const long long b64 = rows * ((W + 63) / 64), b32 = rows * ((W + 31) / 32);
+      auto eff = [](long long blocks) { return (double)blocks / (double)((blocks + 767) / 768 * 768); };
+      if (eff(b32) > 1.15 * eff(b64)) return launch2d<G2<3, 2, 4, 4, false, 2, 3, 2>>(a, s);
+      return launch2d<G2<3, 2, 4, 4, false, 2, 3>>(a, s);
+    }
     return launch2d<G2<3, 1, 4, 4, false, 2, 3>>(a, s);
   }
   if (NT == 2) return launch2d<G2<3, 2, 4, 16, true, 2, 2>>(a, s);   // 9 staged positions per thread: spills at 170 registers
   return launch2d<G2<3, 1, 4, 16, true, 2, 3>>(a, s);
+}
+
+extern "C" int dv_conv2d_f32(const float* in, const float* wpacked, const float* ch_scale, const float* ch_bias,
+                             const float* residual, float* out, int B, int Cin, int H, int W, int Cout, int k,
+                             int dilation, int act, dv_stream_t stream) {
+  return conv2d_run(in, wpacked, ch_scale, ch_bias, residual, nullptr, nullptr, nullptr, out, B, Cin, H, W, Cout, k,
+                    dilation, act, stream);
+}
+
+extern "C" int dv_conv2d_gated_f32(const float* in, const float* wpacked, const float* ch_scale, const float* ch_bias,
+                                   const float* residual, const float* mul, const float* blend_z, const float* blend_h,
+                                   float* out, int B, int Cin, int H, int W, int Cout, int k, int dilation, int act,
+                                   dv_stream_t stream) {
+  return conv2d_run(in, wpacked, ch_scale, ch_bias, residual, mul, blend_z, blend_h, out, B, Cin, H, W, Cout, k,
+                    dilation, act, stream);
 }

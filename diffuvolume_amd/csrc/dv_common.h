@@ -32,6 +32,8 @@ __device__ __forceinline__ float dv_act(float v, int act) {
       return v * tanhf(sp);
     }
     case DV_ACT_LEAKY: return v > 0.0f ? v : 0.01f * v;
+    case DV_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    case DV_ACT_TANH: return tanhf(v);
     default: return v;
   }
 }

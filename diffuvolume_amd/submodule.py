@@ -17,9 +17,9 @@ from .profiling import timed
 
 __all__ = ["build_gwc_volume", "build_concat_volume", "build_concat_attention_volume",
            "disparity_regression", "upsample_softmax_regress", "Conv3dPlan", "Conv2dPlan", "Deconv3dPlan",
-           "window_attention", "feature_gate", "softmax_regress", "refine_inputs", "ACT_NONE", "ACT_RELU", "ACT_MISH", "ACT_LEAKY"]
+           "window_attention", "feature_gate", "softmax_regress", "refine_inputs", "ACT_NONE", "ACT_RELU", "ACT_MISH", "ACT_LEAKY", "ACT_SIGMOID", "ACT_TANH"]
 
-ACT_NONE, ACT_RELU, ACT_MISH, ACT_LEAKY = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_MISH, ACT_LEAKY, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4, 5     # last two: 2-D convs only
 
 
 _CONV_PRECISION = None
@@ -276,12 +276,13 @@ class Conv3dPlan:
 
 
 class Conv2dPlan:
-    """Conv2d(k 3 or 1, stride 1, padding = dilation, bias=False) [+ BatchNorm2d eval] [+ residual] [+ activation]
-    on the 2-D implicit-GEMM kernel: `convbn` / `BasicBlock` of the KITTI12 refinement stack
-    (KITTI12/models/submodule.py:21-24, :192-215)."""
+    """Conv2d(k 3 or 1, stride 1, padding = dilation) [+ bias] [+ BatchNorm2d eval] [+ residual] [+ activation]
+    [+ ConvGRU gate arithmetic] on the 2-D implicit-GEMM kernel: `convbn` / `BasicBlock` of the KITTI12 refinement
+    stack (KITTI12/models/submodule.py:21-24, :192-215) and the biased convolutions of IGEV's update block
+    (KITTI15/core/update.py)."""
 
     def __init__(self, weight: torch.Tensor, bn: Optional[Tuple[torch.Tensor, ...]] = None, dilation: int = 1,
-                 act: int = ACT_NONE, eps: float = 1e-5):
+                 act: int = ACT_NONE, eps: float = 1e-5, bias: Optional[torch.Tensor] = None):
         w = _dev_f32(weight.detach(), "weight")
         self.cout, self.cin, k = w.shape[0], w.shape[1], w.shape[2]
         if tuple(w.shape[2:]) != (k, k) or k not in (1, 3):
@@ -295,26 +296,36 @@ class Conv2dPlan:
         with torch.cuda.device(w.device):
             _lib.check(lib.dv_conv2d_pack_weights_f32(w.data_ptr(), self.wpacked.data_ptr(), self.cin, self.cout, k,
                                                       self.dilation, _lib.stream_ptr()), "conv2d weight packing")
-        self.scale, self.shift = _fold_bn(bn, None, self.cout, w.device, eps)
+        self.scale, self.shift = _fold_bn(bn, bias, self.cout, w.device, eps)
 
-    def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, mul: Optional[torch.Tensor] = None,
+                 blend: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+        """act(conv(x)*scale + shift + residual) [* mul] [-> h + z*(. - h) for blend = (z, h)]."""
         x = _dev_f32(x, "x")
         b, cin, h, w = x.shape
         if cin != self.cin:
             raise RuntimeError(f"expected {self.cin} input channels, got {cin}")
         out = torch.empty((b, self.cout, h, w), dtype=torch.float32, device=x.device)
-        if residual is not None:
-            residual = _dev_f32(residual, "residual")
-            if tuple(residual.shape) != tuple(out.shape):
-                raise RuntimeError("residual shape mismatch")
+
+        def same(t, name):
+            t = _dev_f32(t, name)
+            if tuple(t.shape) != tuple(out.shape):
+                raise RuntimeError(f"{name} shape mismatch")
+            return t
+
+        residual = None if residual is None else same(residual, "residual")
+        mul = None if mul is None else same(mul, "mul")
+        bz, bh = (None, None) if blend is None else (same(blend[0], "blend z"), same(blend[1], "blend h"))
+        extra = sum(t is not None for t in (residual, mul, bz, bh))
         lib = _lib.load()
         with torch.cuda.device(x.device):
-            nb = 4.0 * (x.numel() + out.numel() * (1 if residual is None else 2))
+            nb = 4.0 * (x.numel() + out.numel() * (1 + extra))
             timed(f"conv2d_k{self.k}d{self.dilation}_co{self.cout}", 2.0 * out.numel() * cin * self.k ** 2, nb,
-                  lambda: _lib.check(lib.dv_conv2d_f32(x.data_ptr(), self.wpacked.data_ptr(), _lib.ptr(self.scale),
-                                                       _lib.ptr(self.shift), _lib.ptr(residual), out.data_ptr(), b, cin,
-                                                       h, w, self.cout, self.k, self.dilation, self.act,
-                                                       _lib.stream_ptr()), "dv_conv2d_f32"))
+                  lambda: _lib.check(lib.dv_conv2d_gated_f32(x.data_ptr(), self.wpacked.data_ptr(), _lib.ptr(self.scale),
+                                                             _lib.ptr(self.shift), _lib.ptr(residual), _lib.ptr(mul),
+                                                             _lib.ptr(bz), _lib.ptr(bh), out.data_ptr(), b, cin, h, w,
+                                                             self.cout, self.k, self.dilation, self.act,
+                                                             _lib.stream_ptr()), "dv_conv2d_gated_f32"))
         return out
 
 

@@ -1,0 +1,158 @@
+"""IGEV's recurrent update block (KITTI15/core/update.py) behind the reference's module API: same classes, same
+parameter names (a reference ``update_block`` state_dict loads unchanged), same ``forward`` signature and return
+convention, so ``IGEVDiffusionLoop`` (or the reference's own ``ddim_sample``) can call it in place.
+
+On HIP (csrc/conv2d.hip): every 3x3 / 1x1 convolution with its bias and ReLU / sigmoid / tanh, and the ConvGRU gate
+arithmetic in the epilogues -- ``convr`` emits ``r*h`` directly, ``convq`` emits ``(1-z)*h + z*tanh(.)`` -- so a
+ConvGRU is three launches plus the two input concatenations.  PyTorch: the 7x7 single-channel ``convd1`` (0.2 GFLOP),
+``torch.cat``, average pooling and bilinear interpolation between the three scales.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .submodule import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, Conv2dPlan
+
+
+class _Planned(nn.Module):
+    """Plans (packed weights on the device) are rebuilt after .to() / load_state_dict()."""
+
+    def __init__(self):
+        super().__init__()
+        self._plans = None
+
+    def _apply(self, fn, *a, **k):
+        self._plans = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._plans = None
+        return super().load_state_dict(*a, **k)
+
+    def plans(self):
+        if self._plans is None:
+            self._plans = self._build()
+        return self._plans
+
+
+def _plan(conv: nn.Conv2d, act: int) -> Conv2dPlan:
+    return Conv2dPlan(conv.weight, None, dilation=1, act=act, bias=conv.bias)
+
+
+class DispHead(_Planned):
+    """update.py:15-24."""
+
+    def __init__(self, input_dim=128, hidden_dim=256, output_dim=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
+        self.conv2 = nn.Conv2d(hidden_dim, output_dim, 3, padding=1)
+
+    def _build(self):
+        return _plan(self.conv1, ACT_RELU), _plan(self.conv2, ACT_NONE)
+
+    def forward(self, x):
+        c1, c2 = self.plans()
+        return c2(c1(x))
+
+
+class ConvGRU(_Planned):
+    """update.py:26-40: z, r gates and candidate q from 3x3 convolutions of [h, x]; cz / cr / cq are the
+    per-pair context terms added before the non-linearity."""
+
+    def __init__(self, hidden_dim, input_dim, kernel_size=3):
+        super().__init__()
+        if kernel_size != 3:
+            raise ValueError("ConvGRU is built with 3x3 convolutions in the reference")
+        self.convz = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=kernel_size // 2)
+        self.convr = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=kernel_size // 2)
+        self.convq = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=kernel_size // 2)
+
+    def _build(self):
+        return _plan(self.convz, ACT_SIGMOID), _plan(self.convr, ACT_SIGMOID), _plan(self.convq, ACT_TANH)
+
+    def forward(self, h, cz, cr, cq, *x_list):
+        pz, pr, pq = self.plans()
+        x = torch.cat(x_list, dim=1)
+        hx = torch.cat([h, x], dim=1)
+        z = pz(hx, residual=cz)                         # sigmoid(convz(hx) + cz)
+        rh = pr(hx, residual=cr, mul=h)                 # sigmoid(convr(hx) + cr) * h
+        return pq(torch.cat([rh, x], dim=1), residual=cq, blend=(z, h))     # (1-z)*h + z*tanh(convq(.) + cq)
+
+
+class BasicMotionEncoder(_Planned):
+    """update.py:74-94."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        cor_planes = args.corr_levels * (2 * args.corr_radius + 1) * (8 + 1)
+        self.convc1 = nn.Conv2d(cor_planes, 64, 1, padding=0)
+        self.convc2 = nn.Conv2d(64, 64, 3, padding=1)
+        self.convd1 = nn.Conv2d(1, 64, 7, padding=3)
+        self.convd2 = nn.Conv2d(64, 64, 3, padding=1)
+        self.conv = nn.Conv2d(64 + 64, 128 - 1, 3, padding=1)
+
+    def _build(self):
+        return {n: _plan(getattr(self, n), ACT_RELU) for n in ("convc1", "convc2", "convd2", "conv")}
+
+    def forward(self, disp, corr):
+        p = self.plans()
+        cor = p["convc2"](p["convc1"](corr))
+        disp_ = p["convd2"](F.relu(self.convd1(disp)))
+        out = p["conv"](torch.cat([cor, disp_], dim=1))
+        return torch.cat([out, disp], dim=1)
+
+
+def pool2x(x):
+    return F.avg_pool2d(x, 3, stride=2, padding=1)
+
+
+def pool4x(x):
+    return F.avg_pool2d(x, 5, stride=4, padding=1)
+
+
+def interp(x, dest):
+    return F.interpolate(x, dest.shape[2:], mode="bilinear", align_corners=True)
+
+
+class BasicMultiUpdateBlock(_Planned):
+    """update.py:104-142."""
+
+    def __init__(self, args, hidden_dims=()):
+        super().__init__()
+        self.args = args
+        self.encoder = BasicMotionEncoder(args)
+        encoder_output_dim = 128
+        self.gru04 = ConvGRU(hidden_dims[2], encoder_output_dim + hidden_dims[1] * (args.n_gru_layers > 1))
+        self.gru08 = ConvGRU(hidden_dims[1], hidden_dims[0] * (args.n_gru_layers == 3) + hidden_dims[2])
+        self.gru16 = ConvGRU(hidden_dims[0], hidden_dims[1])
+        self.disp_head = DispHead(hidden_dims[2], hidden_dim=256, output_dim=1)
+        self.mask_feat_4 = nn.Sequential(nn.Conv2d(hidden_dims[2], 32, 3, padding=1), nn.ReLU(inplace=True))
+
+    def _build(self):
+        return _plan(self.mask_feat_4[0], ACT_RELU)
+
+    def forward(self, net, inp, corr=None, disp=None, iter04=True, iter08=True, iter16=True, update=True):
+        if self.training:
+            raise NotImplementedError("the MI355X update block is inference-only (model.eval())")
+        with torch.no_grad():
+            if iter16:
+                net[2] = self.gru16(net[2], *(inp[2]), pool2x(net[1]))
+            if iter08:
+                if self.args.n_gru_layers > 2:
+                    net[1] = self.gru08(net[1], *(inp[1]), pool2x(net[0]), interp(net[2], net[1]))
+                else:
+                    net[1] = self.gru08(net[1], *(inp[1]), pool2x(net[0]))
+            if iter04:
+                motion_features = self.encoder(disp, corr)
+                if self.args.n_gru_layers > 1:
+                    net[0] = self.gru04(net[0], *(inp[0]), motion_features, interp(net[1], net[0]))
+                else:
+                    net[0] = self.gru04(net[0], *(inp[0]), motion_features)
+            if not update:
+                return net
+            delta_disp = self.disp_head(net[0])
+            mask_feat_4 = self.plans()(net[0])
+        return net, mask_feat_4, delta_disp

@@ -34,6 +34,8 @@ typedef void* dv_stream_t; /* hipStream_t */
 #define DV_ACT_RELU 1      /* SceneFlow / ACVNet */
 #define DV_ACT_MISH 2      /* KITTI12 / PCWNet: x*tanh(softplus(x)) */
 #define DV_ACT_LEAKY 3     /* KITTI15 / IGEV: LeakyReLU(0.01) */
+#define DV_ACT_SIGMOID 4   /* ConvGRU gates (KITTI15/core/update.py:36-37); dv_conv2d_* only */
+#define DV_ACT_TANH 5      /* ConvGRU candidate state (update.py:38); dv_conv2d_* only */
 
 int dv_version(void);
 const char* dv_error_string(int code);
@@ -127,6 +129,16 @@ int dv_conv2d_pack_weights_f32(const float* w, float* wpacked, int Cin, int Cout
 int dv_conv2d_f32(const float* in, const float* wpacked, const float* ch_scale, const float* ch_bias,
                   const float* residual, float* out, int B, int Cin, int H, int W, int Cout, int k,
                   int dilation, int act, dv_stream_t stream);
+
+/* The same convolution with the ConvGRU gate arithmetic of KITTI15/core/update.py:26-40 in its epilogue:
+ *   v = act( conv2d(in, w) * ch_scale + ch_bias + residual );
+ *   if (mul)      v = v * mul;                                   r * h            (update.py:38, the `r*h` operand)
+ *   if (blend_z)  v = blend_h + blend_z * (v - blend_h);         (1-z)*h + z*q    (update.py:39)
+ * mul / blend_z / blend_h are [B,Cout,H,W] or NULL; act may also be DV_ACT_SIGMOID / DV_ACT_TANH. */
+int dv_conv2d_gated_f32(const float* in, const float* wpacked, const float* ch_scale, const float* ch_bias,
+                        const float* residual, const float* mul, const float* blend_z, const float* blend_h,
+                        float* out, int B, int Cin, int H, int W, int Cout, int k, int dilation, int act,
+                        dv_stream_t stream);
 
 /* Input assembly of that refinement (KITTI12/models/pwcnet_ddim.py:486-502), fused:
  *   frw = warp(right, disp)  (models/submodule.py:137-176, incl. its align_corners mismatch and >= 0.999 mask),

@@ -190,3 +190,51 @@ def igev_cost_volume(match_left, match_right, features_left, sd, max_disp=192):
     geo = igev_hourglass(gwc, features_left, sd, "cost_agg")
     prob = F.softmax(F.conv3d(geo, sd["classifier.weight"], None, 1, 1).squeeze(1), dim=1)
     return geo, disparity_regression(prob, d4, keepdim=True)
+
+
+# ---------------------------------------------------------------------------------------------------
+# IGEV's recurrent update block (KITTI15/core/update.py), functional restatement over a flat state_dict.
+# ---------------------------------------------------------------------------------------------------
+def _conv(x, sd, p, pad):
+    return F.conv2d(x, sd[p + ".weight"], sd[p + ".bias"], 1, pad)
+
+
+def conv_gru(h, cz, cr, cq, xs, sd, p):
+    """ConvGRU.forward (update.py:33-40)."""
+    x = torch.cat(xs, dim=1)
+    hx = torch.cat([h, x], dim=1)
+    z = torch.sigmoid(_conv(hx, sd, p + ".convz", 1) + cz)
+    r = torch.sigmoid(_conv(hx, sd, p + ".convr", 1) + cr)
+    q = torch.tanh(_conv(torch.cat([r * h, x], dim=1), sd, p + ".convq", 1) + cq)
+    return (1 - z) * h + z * q
+
+
+def motion_encoder(disp, corr, sd, p="encoder"):
+    """BasicMotionEncoder.forward (update.py:85-94)."""
+    cor = F.relu(_conv(corr, sd, p + ".convc1", 0))
+    cor = F.relu(_conv(cor, sd, p + ".convc2", 1))
+    d = F.relu(_conv(disp, sd, p + ".convd1", 3))
+    d = F.relu(_conv(d, sd, p + ".convd2", 1))
+    out = F.relu(_conv(torch.cat([cor, d], dim=1), sd, p + ".conv", 1))
+    return torch.cat([out, disp], dim=1)
+
+
+def update_block(sd, net, inp, corr, disp, n_gru_layers=3, iter04=True, iter08=True, iter16=True, update=True):
+    """BasicMultiUpdateBlock.forward (update.py:123-142); returns a new `net` list (the reference mutates its)."""
+    net = list(net)
+    pool2x = lambda t: F.avg_pool2d(t, 3, stride=2, padding=1)
+    interp = lambda t, dest: F.interpolate(t, dest.shape[2:], mode="bilinear", align_corners=True)
+    if iter16:
+        net[2] = conv_gru(net[2], *inp[2], [pool2x(net[1])], sd, "gru16")
+    if iter08:
+        xs = [pool2x(net[0]), interp(net[2], net[1])] if n_gru_layers > 2 else [pool2x(net[0])]
+        net[1] = conv_gru(net[1], *inp[1], xs, sd, "gru08")
+    if iter04:
+        mf = motion_encoder(disp, corr, sd)
+        xs = [mf, interp(net[1], net[0])] if n_gru_layers > 1 else [mf]
+        net[0] = conv_gru(net[0], *inp[0], xs, sd, "gru04")
+    if not update:
+        return net
+    delta = _conv(F.relu(_conv(net[0], sd, "disp_head.conv1", 1)), sd, "disp_head.conv2", 1)
+    mask = F.relu(_conv(net[0], sd, "mask_feat_4.0", 1))
+    return net, mask, delta

@@ -1,0 +1,74 @@
+"""KITTI15 flavour: IGEV's recurrent update block (ConvGRU x3 scales, motion encoder, heads) on the 2-D HIP
+convolution with the gate arithmetic fused, vs the reference's golden vectors and the oracle."""
+import pytest
+import torch
+
+from conftest import load_golden
+from diffuvolume_amd import submodule as S
+from diffuvolume_amd.synth import _gen
+from oracle import igev_oracle as I
+from test_igev_update_oracle import ARGS, update_inputs, update_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(t):
+    return t.to(DEV)
+
+
+def rel_err(a, b):
+    return float((a.cpu().double() - b.double()).abs().max() / b.double().abs().max().clamp(min=1e-30))
+
+
+def make_block(seed):
+    from diffuvolume_amd.update import BasicMultiUpdateBlock
+    m = BasicMultiUpdateBlock(ARGS, hidden_dims=[128, 128, 128])
+    m.load_state_dict(update_state_dict(seed), strict=True)
+    return m.to(DEV).eval()
+
+
+@pytest.mark.parametrize("act", ["sigmoid", "tanh"])
+def test_conv2d_gate_epilogues(act):
+    """act(conv + bias + residual) [* mul] [blended with (z, h)] -- the ConvGRU arithmetic of update.py:36-39."""
+    g = _gen(111, act)
+    x = torch.randn(2, 40, 11, 70, generator=g)
+    w = torch.randn(32, 40, 3, 3, generator=g) * 0.05
+    bias, res = torch.randn(32, generator=g) * 0.1, torch.randn(2, 32, 11, 70, generator=g)
+    h, z = torch.randn(2, 32, 11, 70, generator=g), torch.rand(2, 32, 11, 70, generator=g)
+    fn = torch.sigmoid if act == "sigmoid" else torch.tanh
+    v = fn(torch.nn.functional.conv2d(x, w, bias, 1, 1) + res)
+    plan = S.Conv2dPlan(dev(w), None, act=S.ACT_SIGMOID if act == "sigmoid" else S.ACT_TANH, bias=dev(bias))
+    torch.testing.assert_close(plan(dev(x), residual=dev(res)).cpu(), v, atol=2e-6, rtol=1e-5)
+    torch.testing.assert_close(plan(dev(x), residual=dev(res), mul=dev(h)).cpu(), v * h, atol=4e-6, rtol=1e-5)
+    torch.testing.assert_close(plan(dev(x), residual=dev(res), blend=(dev(z), dev(h))).cpu(), (1 - z) * h + z * v,
+                               atol=4e-6, rtol=1e-5)
+
+
+def test_update_block_golden():
+    g = load_golden("igev_update")
+    m = make_block(int(g["sd_seed"]))
+    net, inp, corr, disp = update_inputs(int(g["in_seed"]), 1, 16, 24)
+    dnet, dinp = [dev(t) for t in net], [[dev(t) for t in l] for l in inp]
+    n1, mask1, d1 = m([t.clone() for t in dnet], dinp, dev(corr), dev(disp))
+    n1 = [t.clone() for t in n1]
+    n2, mask2, d2 = m([t.clone() for t in n1], dinp, dev(corr), dev(disp) + d1)
+    for i in range(3):
+        assert rel_err(n1[i], g[f"net1_{i}"]) < 1e-5 and rel_err(n2[i], g[f"net2_{i}"]) < 2e-5
+    assert rel_err(mask1, g["mask1"]) < 1e-5 and rel_err(mask2, g["mask2"]) < 2e-5
+    assert rel_err(d1, g["delta1"]) < 1e-5 and rel_err(d2, g["delta2"]) < 3e-5
+    slow = m([t.clone() for t in dnet], dinp, iter04=False, iter08=False, update=False)
+    assert rel_err(slow[2], g["slow_net2"]) < 1e-5
+
+
+def test_update_block_vs_oracle_kitti_aspect_batch2():
+    """1/4 resolution of a 1248-wide frame is 312 columns (not a multiple of the 64-column tile), batch 2."""
+    from diffuvolume_amd.synth import synth_state_dict  # noqa: F401
+    m = make_block(121)
+    sd = update_state_dict(121)
+    net, inp, corr, disp = update_inputs(122, 2, 24, 312)
+    ref_net, ref_mask, ref_delta = I.update_block(sd, net, inp, corr, disp)
+    n, mask, delta = m([dev(t) for t in net], [[dev(t) for t in l] for l in inp], dev(corr), dev(disp))
+    for i in range(3):
+        assert rel_err(n[i], ref_net[i]) < 1e-5
+    assert rel_err(mask, ref_mask) < 1e-5 and rel_err(delta, ref_delta) < 1e-5

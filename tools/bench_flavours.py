@@ -81,6 +81,46 @@ def igev(b=4, h=96, w=312):
         res["geo_lookup_ms"] = timeit(lambda: fn(init, coords, noisy), warmup=2, steps=20)
         res["front_kernels_ms"] = kernels(lambda: m(ml, mr, feats))
     res["lookups_per_pair_cfg5"] = "20 steps x 32 iters = 640 (reference default 2 x 32)"
+    # one GRU iteration of the update block (KITTI15/core/update.py) at the same size: HIP convs with fused gates
+    # vs the same arithmetic written with torch ops (MIOpen convolutions + ATen elementwise)
+    import types
+    from diffuvolume_amd.update import BasicMultiUpdateBlock
+    ub = BasicMultiUpdateBlock(types.SimpleNamespace(corr_levels=2, corr_radius=4, n_gru_layers=3, n_downsample=2),
+                               hidden_dims=[128, 128, 128])
+    ub.load_state_dict(synth_state_dict(ub.state_dict(), seed=101))
+    ub = ub.to(DEV).eval()
+    dims = [(h, w), (h // 2, w // 2), (h // 4, w // 4)]
+    net = [torch.tanh(torch.randn(b, 128, hh, ww, device=DEV)) for hh, ww in dims]
+    inp = [[torch.randn(b, 128, hh, ww, device=DEV) * 0.5 for _ in range(3)] for hh, ww in dims]
+    corr = torch.randn(b, 162, h, w, device=DEV)
+    dsp = torch.rand(b, 1, h, w, device=DEV) * 40
+
+    def torch_gru(g, hh, cz, cr, cq, *xs):
+        x = torch.cat(xs, 1)
+        hx = torch.cat([hh, x], 1)
+        z = torch.sigmoid(g.convz(hx) + cz)
+        r = torch.sigmoid(g.convr(hx) + cr)
+        q = torch.tanh(g.convq(torch.cat([r * hh, x], 1)) + cq)
+        return (1 - z) * hh + z * q
+
+    def torch_update():
+        import torch.nn.functional as F
+        from diffuvolume_amd.update import interp, pool2x
+        n = list(net)
+        n[2] = torch_gru(ub.gru16, n[2], *inp[2], pool2x(n[1]))
+        n[1] = torch_gru(ub.gru08, n[1], *inp[1], pool2x(n[0]), interp(n[2], n[1]))
+        e = ub.encoder
+        cor = F.relu(e.convc2(F.relu(e.convc1(corr))))
+        d_ = F.relu(e.convd2(F.relu(e.convd1(dsp))))
+        mf = torch.cat([F.relu(e.conv(torch.cat([cor, d_], 1))), dsp], 1)
+        n[0] = torch_gru(ub.gru04, n[0], *inp[0], mf, interp(n[1], n[0]))
+        dh = ub.disp_head
+        return n, F.relu(ub.mask_feat_4[0](n[0])), dh.conv2(F.relu(dh.conv1(n[0])))
+
+    with torch.no_grad():
+        res["update_block_hip_ms"] = timeit(lambda: ub(list(net), inp, corr, dsp), warmup=2, steps=10)
+        res["update_block_torch_ms"] = timeit(torch_update, warmup=2, steps=10)
+        res["update_block_kernels_ms"] = kernels(lambda: ub(list(net), inp, corr, dsp))
     return res
 
 

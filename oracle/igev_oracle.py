@@ -71,8 +71,13 @@ def head180_shift(t, sd, bins: int = 48):
 
 
 class IGEVLoopOracle:
-    def __init__(self, head_sd, update_block, upsample_disp, geo, f1, f2, sampling_timesteps=2, cof=(0.6, 0.1, 0.3)):
+    def __init__(self, head_sd, update_block, upsample_disp, geo, f1, f2, sampling_timesteps=2, cof=(0.6, 0.1, 0.3),
+                 net_list=None, inp_list=None):
         from . import acv_oracle as A
+        # hidden states / context terms of the update block; the reference mutates `net_list` in place, so the
+        # hidden state carries over from one DDIM step to the next (igev_stereo_ddim.py:240-250, :318)
+        self.net_list = [None] if net_list is None else list(net_list)
+        self.inp_list = [None] if inp_list is None else inp_list
         self.A, self.head_sd, self.update_block, self.upsample_disp = A, head_sd, update_block, upsample_disp
         self.geo, self.f1, self.f2 = geo, f1, f2
         self.S, self.cof = sampling_timesteps, cof
@@ -87,12 +92,13 @@ class IGEVLoopOracle:
         """:226-292 (n_gru_layers=3, slow_fast_gru=False, flow_init=None)."""
         A = self.A
         n01 = ((torch.clamp(x_t + head180_shift(t, self.head_sd)[:, :, None, None], -1, 1)) + 1) / 2
-        nets = [None]
+        nets = self.net_list
         for itr in range(iters):
             flow = coords1 - coords0
             corr = self.corr_fn(flow, coords1, n01.float())
-            nets, up_mask, delta = self.update_block(nets, [None], corr, flow, iter16=True, iter08=True)
+            nets, up_mask, delta = self.update_block(nets, self.inp_list, corr, flow, iter16=True, iter08=True)
             coords1 = coords1 + delta
+        self.net_list = nets
         pred = self.upsample_disp(coords1 - coords0, up_mask, None)[:, :1]
         b, _, hh, ww = pred.shape
         dn = F.interpolate(torch.clamp(pred, 0, 47), size=(hh // 4, ww // 4), mode="bilinear") / 4

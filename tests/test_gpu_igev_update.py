@@ -72,3 +72,49 @@ def test_update_block_vs_oracle_kitti_aspect_batch2():
     for i in range(3):
         assert rel_err(n[i], ref_net[i]) < 1e-5
     assert rel_err(mask, ref_mask) < 1e-5 and rel_err(delta, ref_delta) < 1e-5
+
+
+def test_ddim_loop_with_the_real_update_block():
+    """IGEVDiffusionLoop.model_predictions / ddim_sample (igev_stereo_ddim.py:226-359) with the HIP update block and
+    the HIP filtered lookup, against the oracle's loop driven by the oracle's update block: the whole per-pair IGEV
+    iteration (filter -> lookup -> motion encoder -> 3 ConvGRUs -> heads -> two-hot -> DDIM update)."""
+    from diffuvolume_amd.geometry_ddim import Combined_Geo_Encoding_Volume
+    from diffuvolume_amd.igev_stereo_ddim import DynamicHead180, IGEVDiffusionLoop
+    from diffuvolume_amd.synth import NoiseTape, synth_state_dict, toy_upsample_disp
+    from diffuvolume_amd.update import BasicMultiUpdateBlock
+    b, h, w = 1, 16, 24
+    sd = update_state_dict(131)
+    sd["disp_head.conv2.weight"] = sd["disp_head.conv2.weight"] * 0.05      # keep the per-iteration step ~1 bin
+    m = BasicMultiUpdateBlock(ARGS, hidden_dims=[128, 128, 128])
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    head = DynamicHead180()
+    head.load_state_dict(synth_state_dict(head.state_dict(), seed=132), strict=True)
+    head = head.eval()
+    net, inp, _, _ = update_inputs(133, b, h, w)
+    geo = torch.randn(b, 8, 48, h, w, generator=_gen(134, "geo"))
+    f1, f2 = torch.randn(b, 16, h, w, generator=_gen(134, "f1")), torch.randn(b, 16, h, w, generator=_gen(134, "f2"))
+    init = torch.rand(b, 1, h, w, generator=_gen(134, "init")) * 40
+    used = torch.nn.functional.interpolate(init * 4, scale_factor=4, mode="bilinear") + 1.5
+    asd = torch.rand(b, 48, h, w, generator=_gen(134, "asd")) * 2 - 1
+    x_t = torch.randn(b, 48, h, w, generator=_gen(134, "xt"))
+    t = torch.full((b,), 999, dtype=torch.long)
+
+    orc = I.IGEVLoopOracle(head.state_dict(), lambda n, i, c, f, **kw: I.update_block(sd, n, i, c, f),
+                           toy_upsample_disp, geo, f1, f2, net_list=net, inp_list=inp)
+    _, xs_ref, pred_ref, c1_ref = orc.model_predictions(init, init, 3, x_t, t)
+    orc = I.IGEVLoopOracle(head.state_dict(), lambda n, i, c, f, **kw: I.update_block(sd, n, i, c, f),
+                           toy_upsample_disp, geo, f1, f2, net_list=net, inp_list=inp)
+    final_ref = orc.ddim_sample(init, init, 2, used, asd, NoiseTape(135))
+
+    geo_fn = Combined_Geo_Encoding_Volume(dev(f1), dev(f2), dev(geo), radius=4, num_levels=2)
+    loop = IGEVDiffusionLoop(head.to(DEV), m, toy_upsample_disp, n_gru_layers=3, slow_fast_gru=False)
+    dinp = [[dev(x) for x in l] for l in inp]
+    _, xs, pred, c1 = loop.model_predictions(dev(init), dev(init), None, 3, [dev(x) for x in net], dinp, geo_fn,
+                                             dev(x_t), dev(t), None)
+    torch.testing.assert_close(c1.cpu(), c1_ref, atol=2e-3, rtol=1e-4)
+    torch.testing.assert_close(pred.cpu(), pred_ref, atol=8e-3, rtol=1e-4)
+    final = loop.ddim_sample(dev(init), dev(init), None, 2, [dev(x) for x in net], dinp, geo_fn, dev(used), dev(asd),
+                             None, noise=NoiseTape(135))
+    d = (final.cpu() - final_ref).abs()
+    assert float(d.median()) < 2e-3 and float(d.mean()) < 5e-2, (float(d.median()), float(d.mean()))

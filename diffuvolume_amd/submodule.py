@@ -86,6 +86,8 @@ def build_gwc_volume(refimg_fea: torch.Tensor, targetimg_fea: torch.Tensor, maxd
     b, c, h, w = ref.shape
     assert c % num_groups == 0          # submodule.py:211
     out = torch.empty((b, num_groups, maxdisp, h, w), dtype=torch.float32, device=ref.device)
+    if out.numel() == 0:                # empty batch / empty image: the reference returns the empty volume
+        return out
     lib = _lib.load()
     with torch.cuda.device(ref.device):
         timed("gwc_volume", 2.0 * out.numel() * (c // num_groups), 4.0 * (2 * ref.numel() + out.numel()),
@@ -105,6 +107,8 @@ def build_concat_volume(refimg_fea: torch.Tensor, targetimg_fea: torch.Tensor, m
         raise RuntimeError(f"feature shapes differ or are not 4-D: {tuple(ref.shape)} vs {tuple(tgt.shape)}")
     b, c, h, w = ref.shape
     out = torch.empty((b, 2 * c, maxdisp, h, w), dtype=torch.float32, device=ref.device)
+    if out.numel() == 0:
+        return out
     lib = _lib.load()
     with torch.cuda.device(ref.device):
         _lib.check(lib.dv_concat_volume_f32(ref.data_ptr(), tgt.data_ptr(), out.data_ptr(), b, c, h, w,
@@ -143,6 +147,8 @@ def disparity_regression(x: torch.Tensor, maxdisp: int, keepdim: bool = False) -
         raise RuntimeError(f"The size of tensor a ({d}) must match the size of tensor b ({maxdisp}) "
                            "at non-singleton dimension 1")
     out = torch.empty((b, h, w), dtype=torch.float32, device=x.device)
+    if out.numel() == 0:
+        return out.unsqueeze(1) if keepdim else out
     lib = _lib.load()
     with torch.cuda.device(x.device):
         _lib.check(lib.dv_disparity_regression_f32(x.data_ptr(), out.data_ptr(), b, d, h, w,

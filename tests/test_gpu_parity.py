@@ -530,3 +530,19 @@ def test_conv2d_oracle(cfg):
                         act={"mish": S.ACT_MISH, "relu": S.ACT_RELU, "none": S.ACT_NONE}[act])
     out = plan(dev(x), residual=None if res is None else dev(res))
     assert out.shape == y.shape and rel_err(out, y) < 1e-5
+
+
+def test_builder_edge_shapes():
+    """Empty batch (the reference returns empty volumes), a single pixel, and maxdisp wider than the image."""
+    e = S.build_gwc_volume(torch.zeros(0, 8, 2, 4, device=DEV), torch.zeros(0, 8, 2, 4, device=DEV), 3, 4)
+    assert tuple(e.shape) == (0, 4, 3, 2, 4)
+    assert tuple(S.build_concat_volume(torch.zeros(0, 8, 2, 4, device=DEV), torch.zeros(0, 8, 2, 4, device=DEV), 3).shape) == (0, 16, 3, 2, 4)
+    assert tuple(S.disparity_regression(torch.zeros(0, 5, 2, 4, device=DEV), 5).shape) == (0, 2, 4)
+    g = _gen(141, "edge")
+    for shape, d, groups in (((1, 8, 1, 1), 4, 2), ((2, 16, 3, 5), 12, 4)):      # W < maxdisp: mostly zero wedge
+        l, r = torch.randn(*shape, generator=g), torch.randn(*shape, generator=g)
+        torch.testing.assert_close(S.build_gwc_volume(dev(l), dev(r), d, groups).cpu(), O.build_gwc_volume(l, r, d, groups),
+                                   atol=1e-6, rtol=1e-6)
+        assert torch.equal(S.build_concat_volume(dev(l), dev(r), d).cpu(), O.build_concat_volume(l, r, d))
+        assert torch.equal(S.build_concat_volume(dev(l), dev(r), d, zero_left=True).cpu(),
+                           O.build_concat_volume(l, r, d, zero_left=True))

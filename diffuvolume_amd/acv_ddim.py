@@ -146,10 +146,11 @@ class _HourglassPlan:
         self.attn = tuple(t.detach().float().contiguous() for t in
                           (ab.qkv_3d.weight, ab.qkv_3d.bias,
                            ab.final1x1.weight.reshape(ab.final1x1.weight.shape[0], -1), ab.final1x1.bias))
-        self.conv5 = Deconv3dPlan(hg.conv5[0].weight, _bn_of(hg.conv5[1]), act=ACT_RELU, eps=hg.conv5[1].eps)
-        self.conv6 = Deconv3dPlan(hg.conv6[0].weight, _bn_of(hg.conv6[1]), act=ACT_RELU, eps=hg.conv6[1].eps)
-        self.redir1 = _plan_cb3(hg.redir1, 1, ACT_NONE)
-        self.redir2 = _plan_cb3(hg.redir2, 1, ACT_NONE)
+        # relu(BN(deconv) + BN(redir(skip))): the 1x1x1 redir convolutions ride inside the transposed convolutions
+        self.conv5 = Deconv3dPlan(hg.conv5[0].weight, _bn_of(hg.conv5[1]), act=ACT_RELU, eps=hg.conv5[1].eps,
+                                  redir=(hg.redir2[0].weight, _bn_of(hg.redir2[1])), redir_eps=hg.redir2[1].eps)
+        self.conv6 = Deconv3dPlan(hg.conv6[0].weight, _bn_of(hg.conv6[1]), act=ACT_RELU, eps=hg.conv6[1].eps,
+                                  redir=(hg.redir1[0].weight, _bn_of(hg.redir1[1])), redir_eps=hg.redir1[1].eps)
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         c1 = self.conv1(x)
@@ -157,8 +158,8 @@ class _HourglassPlan:
         c3 = self.conv3(c2)
         c4 = self.conv4(c3)
         c4 = window_attention(c4, *self.attn, heads=self.heads)
-        c5 = self.conv5(c4, residual=self.redir2(c2))      # relu(deconv+bn + redir2(conv2))
-        return self.conv6(c5, residual=self.redir1(x))     # relu(deconv+bn + redir1(x))
+        c5 = self.conv5(c4, skip=c2)                       # relu(deconv+bn + redir2(conv2))
+        return self.conv6(c5, skip=x)                      # relu(deconv+bn + redir1(x))
 
 
 class _ConvPairPlan:

@@ -46,6 +46,9 @@ struct DeconvArgs {
   const float* ch_scale;
   const float* ch_bias;
   const float* residual;  // [B,Cout,2D,2H,2W] or null
+  const float* skip;      // [B,Cskip,2D,2H,2W] or null: fused 1x1x1 `redir` convolution of the skip tensor
+  const float* rw;        // [Cout][Cskip] redir weights (BN scale folded in)
+  int Cskip;
   float* out;
   int B, Cin, D, H, W, Cout, Coutp;
   int ntx, nty, ntz, nco;
@@ -68,7 +71,12 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
   constexpr int NKS = kKC / 4;                     // k-steps (4 input channels each) per chunk
   constexpr int BV = NKS * kNT;                    // B floats per lane and tap: [ks][n]
   typedef typename VecOf<BV>::type bvec;
-  __shared__ __attribute__((aligned(16))) float smem[G::IN_FLOATS + G::W_FLOATS];
+  // main-loop image (input brick + weights) followed by four wave-private skip tiles for the fused `redir`
+  constexpr int SKP = 4 * 2 * kTW + 32;            // skip-tile channel stride: == 32 (mod 64), k-lanes on disjoint banks
+  constexpr int SK_FLOATS = 8 * SKP;               // 8 channels x 4 output rows x 64 columns per wave
+  __shared__ __attribute__((aligned(16))) float smem[G::IN_FLOATS + G::W_FLOATS + 4 * SK_FLOATS];
+  static_assert((G::IN_FLOATS + G::W_FLOATS + 4 * SK_FLOATS) * 4 <= 80 * 1024, "two blocks per CU");
+  static_assert((G::IN_FLOATS + G::W_FLOATS) % 4 == 0, "skip tiles are written in 16-byte pieces");
   float* in_s = smem;
   float* w_s = smem + G::IN_FLOATS;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -153,12 +161,52 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
   // input offsets a tap can ask for per dimension: K=3 -> {0,+1}, K=4 -> {-1,0,+1}
   constexpr int OMIN = (K == 4) ? -1 : 0, NOFF = (K == 4) ? 3 : 2, NOZ = (K == 4) ? 1 : 2;
 
+  // ---- fused `redir` (acv_ddim.py:81-86, :91-92): out += W_r[cout][cskip] . skip[cskip][output voxel] ----
+  // Extra K-steps of the same GEMM: for parity class (pz,py,px) the A rows are the skip voxels at
+  // (2z+pz, 2y+py, 2x+px).  A wave only needs the four output rows of its own input row, so its skip tile
+  // (8 channels x 4 rows x 64 columns) is wave-private: it is filled by LDS-DMA (global_load_lds, one 1-KB
+  // instruction per channel, lane-linear image, no staging registers) at the top of a chunk and consumed after
+  // that chunk's main MFMA stream -- no extra block barrier, no separate launch, and the 1x1x1 result never
+  // goes through HBM.  Chunk c of the main loop carries skip channels 8c .. 8c+7.
+  float* sk = smem + G::IN_FLOATS + G::W_FLOATS + wave * SK_FLOATS;
+  const int nsk = a.skip ? (a.Cskip + 7) / 8 : 0;
+  const int rr = lane >> 4, xq = (lane & 15) * 4;                      // this lane's skip row (pz,py) and column quad
+  const size_t ovol2 = 8 * vol;
+  const bool lok = nsk > 0 && (z0 + zl) < a.D && (y0 + yl) < a.H && 2 * x0 + xq < 2 * a.W;   // 2W % 8 == 0: quad all in / out
+  const float* skl = nullptr;
+  if (nsk > 0) {
+#pragma unroll
+    for (int i = 0; i < SK_FLOATS / 256; ++i)                           // masked lanes / channels must read zeros
+      *reinterpret_cast<f32x4*>(sk + i * 256 + lane * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int oz = 2 * (z0 + zl) + (rr >> 1), oy = 2 * (y0 + yl) + (rr & 1);
+    skl = a.skip + (size_t)b * a.Cskip * ovol2 + (lok ? ((size_t)oz * (2 * a.H) + oy) * (2 * a.W) + 2 * x0 + xq : 0);
+  }
+  static_assert(SK_FLOATS % 256 == 0, "zero fill covers the tile");
+
   fetch(0);
   for (int c = 0; c < nchunk; ++c) {
     __syncthreads();
     commit(c);
     __syncthreads();
     if (c + 1 < nchunk) fetch(c + 1);
+    float bw[2][kNT];
+    if (c < nsk) {
+      if (lok) {
+#pragma unroll
+        for (int cl = 0; cl < 8; ++cl)
+          if (c * 8 + cl < a.Cskip)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(skl + (size_t)(c * 8 + cl) * ovol2),
+                (__attribute__((address_space(3))) void*)(sk + cl * SKP), 16, 0, 0);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int n = 0; n < kNT; ++n) {
+          const int co = co0 + n * 16 + j, cs = c * 8 + ks * 4 + kq;
+          bw[ks][n] = (co < a.Cout && cs < a.Cskip) ? a.rw[(size_t)co * a.Cskip + cs] : 0.f;
+        }
+    }
     // A fragments live in registers: every (z,y,x) input shift a tap can ask for x k-steps x M-tiles is read
     // from LDS once (K=3: all 8 shifts per chunk; K=4: the 9 (y,x) shifts of one z shift, reloaded when kz
     // changes slab), so the MFMA stream only needs one vector B read per tap, and that read is issued one tap
@@ -203,6 +251,27 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
                     av[zs][tap_off(ky) - OMIN][tap_off(kx) - OMIN][ks][m], bq[tap & 1][ks * kNT + n], acc[m][cls][n], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    if (c < nsk) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the LDS-DMA of this chunk has landed (long ago)
+      const float* skr = sk + kq * SKP + 2 * j;
+#pragma unroll
+      for (int cls = 0; cls < 8; ++cls) {
+        float sa[2][kMTX];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int m = 0; m < kMTX; ++m) sa[ks][m] = skr[ks * 4 * SKP + (cls >> 1) * (2 * kTW) + m * 32 + (cls & 1)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int m = 0; m < kMTX; ++m)
+#pragma unroll
+            for (int n = 0; n < kNT; ++n)
+              acc[m][cls][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[ks][m], bw[ks][n], acc[m][cls][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
 
@@ -386,8 +455,9 @@ int pack_any(const float* w, float* wpacked, int Cin, int Cout, int K, hipStream
 
 int run_any(const float* in, const float* wpacked, const float* ch_scale, const float* ch_bias,
             const float* residual, float* out, int B, int Cin, int D, int H, int W, int Cout, int act, int K,
-            hipStream_t s) {
+            hipStream_t s, const float* skip = nullptr, const float* rw = nullptr, int Cskip = 0) {
   DeconvArgs a;
+  a.skip = skip; a.rw = rw; a.Cskip = Cskip;
   a.in = in; a.wpk = wpacked; a.ch_scale = ch_scale; a.ch_bias = ch_bias; a.residual = residual;
   a.out = out; a.B = B; a.Cin = Cin; a.D = D; a.H = H; a.W = W; a.Cout = Cout;
   a.Coutp = pad_to(Cout, kCOUT);
@@ -449,4 +519,20 @@ extern "C" int dv_deconv3d_k4s2_f32(const float* in, const float* wpacked, const
                                     int Cin, int D, int H, int W, int Cout, int act, dv_stream_t stream) {
   DV_DECONV_CHECKS
   return run_any(in, wpacked, ch_scale, ch_bias, residual, out, B, Cin, D, H, W, Cout, act, 4, (hipStream_t)stream);
+}
+
+extern "C" int dv_deconv3d_k3s2_redir_f32(const float* in, const float* wpacked, const float* ch_bias,
+                                          const float* skip, const float* redir_w, float* out, int B, int Cin,
+                                          int D, int H, int W, int Cout, int Cskip, int act, dv_stream_t stream) {
+  const float* ch_scale = nullptr;
+  const float* residual = nullptr;
+  (void)ch_scale; (void)residual;
+  DV_DECONV_CHECKS
+  DV_REQUIRE_PTR(skip);
+  DV_REQUIRE_PTR(redir_w);
+  DV_REQUIRE(Cskip > 0, DV_ERR_SHAPE);
+  DV_REQUIRE(W % 4 == 0 && dv_aligned16(skip), DV_ERR_UNSUPPORTED);     // 16-byte skip quads never straddle a row end
+  DV_REQUIRE((Cskip + 7) / 8 <= (Cin + 7) / 8, DV_ERR_UNSUPPORTED);       // skip chunks ride on the main chunks
+  return run_any(in, wpacked, nullptr, ch_bias, nullptr, out, B, Cin, D, H, W, Cout, act, 3, (hipStream_t)stream, skip,
+                 redir_w, Cskip);
 }

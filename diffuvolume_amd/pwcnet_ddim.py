@@ -192,8 +192,12 @@ class Hourglass(nn.Module):
 
 
 # ---- prepared hot-path layers ---------------------------------------------------------------------
-def _deconv_plan(seq, act):
-    return Deconv3dPlan(seq[0].weight, _bn_of(seq[1]), act=act, eps=seq[1].eps)
+def _deconv_plan(seq, act, redir=None):
+    """ConvTranspose3d + BN [+ the 1x1x1 `redir` conv + BN of the skip tensor folded into the same launch]."""
+    if redir is None:
+        return Deconv3dPlan(seq[0].weight, _bn_of(seq[1]), act=act, eps=seq[1].eps)
+    return Deconv3dPlan(seq[0].weight, _bn_of(seq[1]), act=act, eps=seq[1].eps,
+                        redir=(redir[0].weight, _bn_of(redir[1])), redir_eps=redir[1].eps)
 
 
 class _HourglassPlan:
@@ -202,10 +206,10 @@ class _HourglassPlan:
         self.conv2 = _plan_cb3(hg.conv2[0], 1, ACT_MISH)
         self.conv3 = _plan_cb3(hg.conv3[0], 2, ACT_MISH)
         self.conv4 = _plan_cb3(hg.conv4[0], 1, ACT_MISH)
-        self.conv5 = _deconv_plan(hg.conv5, ACT_MISH)
-        self.conv6 = _deconv_plan(hg.conv6, ACT_MISH)
+        self.conv5 = _deconv_plan(hg.conv5, ACT_MISH, hg.redir2)
+        self.conv6 = _deconv_plan(hg.conv6, ACT_MISH, hg.redir1)
+        self.conv6_plain = _deconv_plan(hg.conv6, ACT_MISH)        # filtered skip (first hourglass of a step)
         self.redir1 = _plan_cb3(hg.redir1, 1, ACT_NONE)
-        self.redir2 = _plan_cb3(hg.redir2, 1, ACT_NONE)
 
     def __call__(self, x, in_scale=None):
         """``in_scale`` is the [0,1] volume filter: the reference feeds ``volume * noise`` to conv1 AND to
@@ -213,8 +217,10 @@ class _HourglassPlan:
         c1 = self.conv1(x, in_scale=in_scale)
         c2 = self.conv2(c1)
         c4 = self.conv4(self.conv3(c2))
-        c5 = self.conv5(c4, residual=self.redir2(c2))                       # FMish(deconv + redir2)
-        return self.conv6(c5, residual=self.redir1(x, in_scale=in_scale))   # FMish(deconv + redir1)
+        c5 = self.conv5(c4, skip=c2)                                        # FMish(deconv + redir2)
+        if in_scale is None:
+            return self.conv6(c5, skip=x)                                   # FMish(deconv + redir1)
+        return self.conv6_plain(c5, residual=self.redir1(x, in_scale=in_scale))
 
 
 class _HourglassUpPlan:
@@ -228,12 +234,9 @@ class _HourglassUpPlan:
         self.combine1 = _plan_cb3(m.combine1[0], 1, ACT_MISH)
         self.combine2 = _plan_cb3(m.combine2[0], 1, ACT_MISH)
         self.combine3 = _plan_cb3(m.combine3[0], 1, ACT_MISH)
-        self.conv7 = _deconv_plan(m.conv7, ACT_MISH)
-        self.conv8 = _deconv_plan(m.conv8, ACT_MISH)
-        self.conv9 = _deconv_plan(m.conv9, ACT_MISH)
-        self.redir1 = _plan_cb3(m.redir1, 1, ACT_NONE)
-        self.redir2 = _plan_cb3(m.redir2, 1, ACT_NONE)
-        self.redir3 = _plan_cb3(m.redir3, 1, ACT_NONE)
+        self.conv7 = _deconv_plan(m.conv7, ACT_MISH, m.redir3)
+        self.conv8 = _deconv_plan(m.conv8, ACT_MISH, m.redir2)
+        self.conv9 = _deconv_plan(m.conv9, ACT_MISH, m.redir1)
 
     def __call__(self, x, f4, f5, f6):
         c1 = self.combine1(torch.cat((self.conv1(x), f4), dim=1))
@@ -242,9 +245,9 @@ class _HourglassUpPlan:
         c4 = self.conv4(c3)
         c5 = self.combine3(torch.cat((self.conv5(c4), f6), dim=1))
         c6 = self.conv6(c5)
-        c7 = self.conv7(c6, residual=self.redir3(c4))
-        c8 = self.conv8(c7, residual=self.redir2(c2))
-        return self.conv9(c8, residual=self.redir1(x))
+        c7 = self.conv7(c6, skip=c4)
+        c8 = self.conv8(c7, skip=c2)
+        return self.conv9(c8, skip=x)
 
 
 class _PairPlan:

@@ -338,10 +338,15 @@ class Conv2dPlan:
 class Deconv3dPlan:
     """ConvTranspose3d(stride 2, padding 1, bias=False) + BatchNorm3d (eval) + skip add + activation that
     doubles every dimension: kernel 3 with output_padding 1 (acv_ddim.py:74-80, :91-92) or kernel 4
-    (IGEV hourglass, igev_stereo_ddim.py:44-51)."""
+    (IGEV hourglass, igev_stereo_ddim.py:44-51).
+
+    ``redir=(weight [Cout,Cskip,1,1,1], bn)``: the hourglass's 1x1x1 skip convolution + BN
+    (acv_ddim.py:81-86).  Then ``plan(x, skip=t)`` computes ``act(BN(deconv(x)) + BN_r(conv1x1(t)))`` in one
+    launch (both BN scales folded into the weights, the 1x1x1 product accumulated as extra K-steps); shapes the
+    fused kernel does not take fall back to the two-launch form."""
 
     def __init__(self, weight: torch.Tensor, bn: Optional[Tuple[torch.Tensor, ...]] = None,
-                 act: int = ACT_NONE, eps: float = 1e-5):
+                 act: int = ACT_NONE, eps: float = 1e-5, redir=None, redir_eps: float = 1e-5):
         w = _dev_f32(weight.detach(), "weight")
         self.cin, self.cout, k = w.shape[0], w.shape[1], w.shape[2]
         if tuple(w.shape[2:]) != (k, k, k) or k not in (3, 4):
@@ -352,18 +357,56 @@ class Deconv3dPlan:
             (lib.dv_deconv3d_packed_floats, lib.dv_deconv3d_pack_weights_f32, lib.dv_deconv3d_k3s2_f32, "dv_deconv3d_k3s2_f32")
             if k == 3 else
             (lib.dv_deconv3d_k4_packed_floats, lib.dv_deconv3d_k4_pack_weights_f32, lib.dv_deconv3d_k4s2_f32, "dv_deconv3d_k4s2_f32"))
+        self.scale, self.shift = _fold_bn(bn, None, self.cout, w.device, eps)
+        self.redir_w = self.redir_plan = None
+        if redir is not None:
+            if k != 3:
+                raise _lib.DiffuVolumeError("the fused skip convolution exists for the kernel-3 flavour")
+            rw, rbn = redir
+            rw = _dev_f32(rw.detach(), "redir weight")
+            if rw.shape[0] != self.cout or tuple(rw.shape[2:]) != (1, 1, 1):
+                raise _lib.DiffuVolumeError("redir must be a 1x1x1 convolution onto the deconvolution's channels")
+            self.cskip = rw.shape[1]
+            rscale, rshift = _fold_bn(rbn, None, self.cout, w.device, redir_eps)
+            one = torch.ones(self.cout, device=w.device)
+            zero = torch.zeros(self.cout, device=w.device)
+            sd, sr = (one if self.scale is None else self.scale), (one if rscale is None else rscale)
+            # fold both BN scales into the weights; the fused kernel then needs a single accumulator
+            w = w * sd.view(1, -1, 1, 1, 1)
+            self.redir_w = (rw.reshape(self.cout, self.cskip) * sr.view(-1, 1)).contiguous()
+            self.shift = ((zero if self.shift is None else self.shift) + (zero if rshift is None else rshift)).contiguous()
+            self.scale = None
+            self.redir_plan = Conv3dPlan(self.redir_w.view(self.cout, self.cskip, 1, 1, 1), None, stride=1, act=ACT_NONE,
+                                         precision="f32")       # two-launch fallback
         self.wpacked = torch.empty(sizer(self.cin, self.cout), dtype=torch.float32, device=w.device)
         with torch.cuda.device(w.device):
-            _lib.check(packer(w.data_ptr(), self.wpacked.data_ptr(), self.cin, self.cout, _lib.stream_ptr()),
+            _lib.check(packer(w.contiguous().data_ptr(), self.wpacked.data_ptr(), self.cin, self.cout, _lib.stream_ptr()),
                        "deconv weight packing")
-        self.scale, self.shift = _fold_bn(bn, None, self.cout, w.device, eps)
 
-    def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None,
+                 skip: Optional[torch.Tensor] = None) -> torch.Tensor:
         x = _dev_f32(x, "x")
         b, cin, d, h, w = x.shape
         if cin != self.cin:
             raise RuntimeError(f"expected {self.cin} input channels, got {cin}")
         out = torch.empty((b, self.cout, 2 * d, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+        if skip is not None:
+            if self.redir_w is None or residual is not None:
+                raise RuntimeError("skip= needs a plan built with redir=, and excludes residual=")
+            skip = _dev_f32(skip, "skip")
+            if tuple(skip.shape) != (b, self.cskip, 2 * d, 2 * h, 2 * w):
+                raise RuntimeError("skip shape mismatch")
+            if w % 4 == 0 and (self.cskip + 7) // 8 <= (cin + 7) // 8:
+                lib = _lib.load()
+                with torch.cuda.device(x.device):
+                    nb = 4.0 * (x.numel() + out.numel() + skip.numel())
+                    timed("deconv3d_k3s2_redir", 2.0 * x.numel() * self.cout * 27 + 2.0 * out.numel() * self.cskip, nb,
+                          lambda: _lib.check(lib.dv_deconv3d_k3s2_redir_f32(
+                              x.data_ptr(), self.wpacked.data_ptr(), _lib.ptr(self.shift), skip.data_ptr(),
+                              self.redir_w.data_ptr(), out.data_ptr(), b, cin, d, h, w, self.cout, self.cskip, self.act,
+                              _lib.stream_ptr()), "dv_deconv3d_k3s2_redir_f32"))
+                return out
+            residual = self.redir_plan(skip)
         if residual is not None:
             residual = _dev_f32(residual, "residual")
             if tuple(residual.shape) != tuple(out.shape):

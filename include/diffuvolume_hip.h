@@ -155,6 +155,17 @@ int dv_refine_inputs_f32(const float* left, const float* right, const float* dis
 int dv_feature_gate_f32(const float* cv /*[B,C,D,H,W]*/, const float* logit /*[B,C,H,W]*/, float* out,
                         int B, int C, int D, int H, int W, dv_stream_t stream);
 
+/* The hourglass tail `F.relu(conv6(x) + redir1(skip))` (SceneFlow/models/acv_ddim.py:81-86, :91-92; KITTI12
+ * pwcnet_ddim.py:236-248 with Mish) in ONE launch: the 1x1x1 `redir` convolution of the skip tensor is folded into
+ * the transposed convolution as extra K-steps.
+ *   out = act( deconv3d_k3s2(in, w) + redir_w . skip + ch_bias )
+ * Both BatchNorm scales must already be folded into `w` (before dv_deconv3d_pack_weights_f32) and `redir_w`
+ * ([Cout][Cskip] row-major, device), their shifts summed into ch_bias.  skip [B,Cskip,2D,2H,2W].
+ * Needs W % 4 == 0 and ceil(Cskip/8) <= ceil(Cin/8); otherwise DV_ERR_UNSUPPORTED (run the two layers apart). */
+int dv_deconv3d_k3s2_redir_f32(const float* in, const float* wpacked, const float* ch_bias, const float* skip,
+                               const float* redir_w, float* out, int B, int Cin, int D, int H, int W, int Cout,
+                               int Cskip, int act, dv_stream_t stream);
+
 /* attention_block.forward: SceneFlow/models/submodule.py:398-429 -- 4x4x4 window
  * multi-head self-attention (heads x C/heads), qkv Linear(C,3C)+bias, softmax,
  * final 1x1x1 Conv3d(C,C)+bias.  x [B,C,D,H,W] -> out same shape.  D must be a

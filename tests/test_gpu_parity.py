@@ -546,3 +546,32 @@ def test_builder_edge_shapes():
         assert torch.equal(S.build_concat_volume(dev(l), dev(r), d).cpu(), O.build_concat_volume(l, r, d))
         assert torch.equal(S.build_concat_volume(dev(l), dev(r), d, zero_left=True).cpu(),
                            O.build_concat_volume(l, r, d, zero_left=True))
+
+
+@pytest.mark.parametrize("cfg", [
+    # cin, cout, cskip, (B, D, H, W), act
+    (64, 32, 32, (1, 4, 6, 32), "relu"),
+    (128, 64, 64, (2, 3, 5, 20), "relu"),          # ragged x tile, two cout blocks
+    (64, 32, 32, (1, 2, 3, 36), "mish"),
+    (32, 32, 32, (1, 3, 4, 10), "relu"),           # W % 4 != 0 -> two-launch fallback inside the plan
+    (16, 32, 32, (1, 2, 2, 8), "relu"),            # more skip chunks than input chunks -> fallback
+])
+def test_deconv_fused_redir(cfg):
+    """F.relu(BN(ConvTranspose3d(x)) + BN(Conv3d_1x1x1(skip))) -- the hourglass tail (acv_ddim.py:81-92) in one launch."""
+    cin, cout, cskip, dims, act = cfg
+    g = _gen(51, str(cfg))
+    x = torch.randn(dims[0], cin, *dims[1:], generator=g)
+    skip = torch.randn(dims[0], cskip, *(2 * d for d in dims[1:]), generator=g)
+    w = torch.randn(cin, cout, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5
+    wr = torch.randn(cout, cskip, 1, 1, 1, generator=g) * (1.0 / cskip) ** 0.5
+    bn = lambda: (torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1,
+                  torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5)
+    bnd, bnr = bn(), bn()
+    f = torch.nn.functional
+    y = f.batch_norm(f.conv_transpose3d(x, w, None, 2, 1, 1), bnd[2], bnd[3], bnd[0], bnd[1], False, 0.0, 1e-5) \
+        + f.batch_norm(f.conv3d(skip, wr), bnr[2], bnr[3], bnr[0], bnr[1], False, 0.0, 1e-5)
+    y = torch.relu(y) if act == "relu" else y * torch.tanh(f.softplus(y))
+    plan = S.Deconv3dPlan(dev(w), tuple(dev(t) for t in bnd), act=S.ACT_RELU if act == "relu" else S.ACT_MISH,
+                          redir=(dev(wr), tuple(dev(t) for t in bnr)))
+    out = plan(dev(x), skip=dev(skip))
+    assert out.shape == y.shape and rel_err(out, y) < 1e-5

@@ -121,6 +121,18 @@ def igev(b=4, h=96, w=312):
         res["update_block_hip_ms"] = timeit(lambda: ub(list(net), inp, corr, dsp), warmup=2, steps=10)
         res["update_block_torch_ms"] = timeit(torch_update, warmup=2, steps=10)
         res["update_block_kernels_ms"] = kernels(lambda: ub(list(net), inp, corr, dsp))
+        # the whole per-batch DDIM loop at the reference's defaults (2 DDIM steps) and 32 GRU iterations per step
+        from diffuvolume_amd.igev_stereo_ddim import DynamicHead180, IGEVDiffusionLoop
+        from diffuvolume_amd.synth import toy_upsample_disp
+        head = DynamicHead180()
+        head.load_state_dict(synth_state_dict(head.state_dict(), seed=81))
+        loop = IGEVDiffusionLoop(head.to(DEV).eval(), ub, toy_upsample_disp, n_gru_layers=3, slow_fast_gru=False)
+        used = torch.nn.functional.interpolate(init * 4, scale_factor=4, mode="bilinear")
+        asd = torch.rand(b, 48, h, w, device=DEV) * 2 - 1
+        run = lambda: loop.ddim_sample(init, init, None, 32, list(net), inp, fn, used, asd, None)
+        res["ddim_loop_2steps_32iters_ms"] = timeit(run, warmup=1, steps=2)
+        res["ddim_loop_pairs_per_s_2steps"] = b / (res["ddim_loop_2steps_32iters_ms"] / 1e3)
+        res["ddim_loop_pairs_per_s_20steps_extrapolated"] = b / (10 * res["ddim_loop_2steps_32iters_ms"] / 1e3)
     return res
 
 

@@ -1,8 +1,8 @@
 """GPU diagnostic: DDIM-loop error of HIP and of the fp32 oracle against a float64 oracle run."""
 import sys
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
-sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tests"))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2] / "tests"))
 import torch
 import diffuvolume_amd as dv
 from conftest import load_golden

@@ -1,7 +1,7 @@
 """GPU diagnostic: stage-by-stage error of the HIP aggregation stack against the CPU oracle."""
 import sys
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 import torch
 import diffuvolume_amd as dv
 from diffuvolume_amd.synth import _gen, synth_state_dict

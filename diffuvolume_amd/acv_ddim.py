@@ -27,7 +27,7 @@ from torch import nn
 
 from . import _lib
 from .head import DynamicHead
-from .submodule import (ACT_NONE, ACT_RELU, Conv3dPlan, Deconv3dPlan, _dev_f32,
+from .submodule import (ACT_NONE, ACT_RELU, Conv2dPlan, Conv3dPlan, Deconv3dPlan, _dev_f32,
                         build_concat_attention_volume, build_gwc_volume, check_split_overflow,
                         default_conv_precision, upsample_softmax_regress, window_attention)
 
@@ -65,8 +65,28 @@ class _ResBlock2d(nn.Module):
         return y + (x if self.downsample is None else self.downsample(x))
 
 
+def _plan_cb2(seq: nn.Sequential, act: int) -> Conv2dPlan:
+    """convbn 2-D (Conv2d + BatchNorm2d, submodule.py:21-24 analogue) -> fused plan (stride 1 or 2)."""
+    conv, bn = seq[0], seq[1]
+    return Conv2dPlan(conv.weight, (bn.weight, bn.bias, bn.running_mean, bn.running_var), dilation=conv.dilation[0],
+                      act=act, eps=bn.eps, stride=conv.stride[0])
+
+
+class _ResBlock2dPlan:
+    """BasicBlock: convbn+ReLU, convbn, `out += x` (x through the 1x1 downsample when shape changes)."""
+
+    def __init__(self, blk: _ResBlock2d):
+        self.conv1 = _plan_cb2(blk.conv1[0], ACT_RELU)
+        self.conv2 = _plan_cb2(blk.conv2, ACT_NONE)
+        self.down = None if blk.downsample is None else _plan_cb2(blk.downsample, ACT_NONE)
+
+    def __call__(self, x):
+        return self.conv2(self.conv1(x), residual=x if self.down is None else self.down(x))
+
+
 class FeatureExtraction(nn.Module):
-    """2-D feature CNN (acv_ddim.py:14-53): 320-channel 1/4-resolution ``gwc_feature``."""
+    """2-D feature CNN (acv_ddim.py:14-53): 320-channel 1/4-resolution ``gwc_feature``.  On the GPU (eval) all 55
+    convolutions run on the 2-D implicit-GEMM kernel with BN / ReLU / the residual add fused (csrc/conv2d.hip)."""
 
     def __init__(self):
         super().__init__()
@@ -78,6 +98,7 @@ class FeatureExtraction(nn.Module):
         self.layer2 = self._stack(64, 16, 2, 1, 1)
         self.layer3 = self._stack(128, 3, 1, 1, 1)
         self.layer4 = self._stack(128, 3, 1, 1, 2)
+        self._plans = None
 
     def _stack(self, planes, blocks, stride, pad, dil):
         down = None
@@ -88,12 +109,45 @@ class FeatureExtraction(nn.Module):
         layers += [_ResBlock2d(planes, planes, 1, None, pad, dil) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
+    def _apply(self, fn, *a, **k):
+        self._plans = None
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._plans = None
+        return super()._load_from_state_dict(*a, **k)
+
+    def train(self, mode: bool = True):
+        self._plans = None
+        return super().train(mode)
+
+    def prepare(self):
+        if self._plans is None:
+            with torch.no_grad():
+                first = [_plan_cb2(self.firstconv[i], ACT_RELU) for i in (0, 2, 4)]
+                stacks = [[_ResBlock2dPlan(b) for b in getattr(self, n)] for n in ("layer1", "layer2", "layer3", "layer4")]
+            self._plans = (first, stacks)
+        return self._plans
+
     def forward(self, x):
-        x = self.layer1(self.firstconv(x))
-        l2 = self.layer2(x)
-        l3 = self.layer3(l2)
-        l4 = self.layer4(l3)
-        return {"gwc_feature": torch.cat((l2, l3, l4), dim=1)}
+        if not x.is_cuda:
+            raise _lib.DiffuVolumeError(f"input is on {x.device}: the feature CNN runs on the MI355X (no CPU fallback)")
+        if self.training or (torch.is_grad_enabled() and x.requires_grad):
+            x = self.layer1(self.firstconv(x))          # training / autograd: the plain PyTorch modules, on the GPU
+            l2 = self.layer2(x)
+            l3 = self.layer3(l2)
+            l4 = self.layer4(l3)
+            return {"gwc_feature": torch.cat((l2, l3, l4), dim=1)}
+        first, stacks = self.prepare()
+        with torch.no_grad():
+            for p in first:
+                x = p(x)
+            outs = []
+            for stack in stacks:
+                for blk in stack:
+                    x = blk(x)
+                outs.append(x)
+        return {"gwc_feature": torch.cat(outs[1:], dim=1)}
 
 
 class _WindowAttention(nn.Module):

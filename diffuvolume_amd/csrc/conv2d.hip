@@ -25,12 +25,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 
-__host__ __device__ constexpr int plane_pad(int n) {   // smallest p > n with p % 32 == 16 (bank rule + a spare slot)
-  return (n + 1) + ((16 - (n + 1) % 32) + 32) % 32;
+// LDS channel-plane stride: > n (a spare slot) and such that the 4 k-lanes of an A read hit disjoint banks:
+// == 16 (mod 32) for unit-stride reads, odd for the stride-2 reads of a strided convolution
+__host__ __device__ constexpr int plane_pad(int n, int stride = 1) {
+  return stride == 1 ? (n + 1) + ((16 - (n + 1) % 32) + 32) % 32 : ((n + 1) | 1);
 }
 
-template <int KS_, int NT_, int KC_, int DMAX_, bool BANDED_, int RPW_, int WPS_ = 2, int MTX_ = 4>
+template <int KS_, int NT_, int KC_, int DMAX_, bool BANDED_, int RPW_, int WPS_ = 2, int MTX_ = 4, int S_ = 1>
 struct G2 {
+  static constexpr int S = S_;         // stride (2: the down-sampling layers of the 2-D feature CNNs)
   static constexpr int WPS = WPS_;     // blocks per CU the register budget is set for
   static constexpr int MTX = MTX_, TW = MTX_ * 16;     // M tiles (16 columns each) per row
   static constexpr int KS = KS_, NT = NT_, KC = KC_, DMAX = DMAX_;
@@ -40,9 +43,10 @@ struct G2 {
   static constexpr int BV = NKS * NT;                 // B floats per lane and tap: [ks][n]
   static constexpr int VW = BV < 4 ? BV : 4;          // floats per LDS read
   static constexpr int Q = BV / VW;
-  static constexpr int RMAX = BANDED ? 3 * TH : TH + (KS - 1) * DMAX;
-  static constexpr int CMAX = TW + (KS - 1) * DMAX;
-  static constexpr int PMAX = plane_pad(RMAX * CMAX);
+  static constexpr int RMAX = BANDED ? 3 * TH : (TH - 1) * S + 1 + (KS - 1) * DMAX;
+  static constexpr int CMAX = (TW - 1) * S + 1 + (KS - 1) * DMAX;
+  static_assert(!(BANDED && S != 1), "banded staging is stride 1");
+  static constexpr int PMAX = plane_pad(RMAX * CMAX, S);
   static constexpr int IN_FLOATS = KC * PMAX, W_FLOATS = T * KC * COUT;
   static_assert(BV == 1 || BV == 2 || BV % 4 == 0, "B vector width");
   static_assert((IN_FLOATS + W_FLOATS) * 4 * WPS <= 160 * 1024, "WPS blocks per CU");
@@ -59,6 +63,7 @@ struct Conv2dArgs {
   const float* blend_h;
   float* out;             // [B,Cout,H,W]
   int B, Cin, H, W, Cout;
+  int Ho, Wo;             // output size (= H, W for stride 1)
   int dil;                // dilation (= padding); 0 for 1x1
   int ntx, nty, nco;
   int act, vec_store, fast_ok;
@@ -67,7 +72,7 @@ struct Conv2dArgs {
 template <class G>
 __global__ __launch_bounds__(256, G::WPS) void conv2d_mfma_kernel(Conv2dArgs a) {
   constexpr int KS = G::KS, NT = G::NT, KC = G::KC, NKS = G::NKS, BV = G::BV, VW = G::VW, Q = G::Q, T = G::T;
-  constexpr int TH = G::TH, RPW = G::RPW, MT = G::MT, MTX = G::MTX, TW = G::TW;
+  constexpr int TH = G::TH, RPW = G::RPW, MT = G::MT, MTX = G::MTX, TW = G::TW, S = G::S;
   __shared__ __attribute__((aligned(16))) float smem[G::IN_FLOATS + G::W_FLOATS];
   float* in_s = smem;
   float* w_s = smem + G::IN_FLOATS;
@@ -82,9 +87,9 @@ __global__ __launch_bounds__(256, G::WPS) void conv2d_mfma_kernel(Conv2dArgs a) 
   const int b = t / a.nco;
   const int x0 = tx * TW, y0 = ty * TH, co0 = tc * G::COUT;
   const int d = a.dil;
-  const int C = TW + (KS - 1) * d;                        // staged columns
-  const int R = G::BANDED ? 3 * TH : TH + (KS - 1) * d;   // staged rows
-  const int P = plane_pad(R * C);                         // channel plane stride in LDS (== 16 mod 32)
+  const int C = (TW - 1) * S + 1 + (KS - 1) * d;                        // staged columns
+  const int R = G::BANDED ? 3 * TH : (TH - 1) * S + 1 + (KS - 1) * d;   // staged rows
+  const int P = plane_pad(R * C, S);                                    // channel plane stride in LDS
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -104,8 +109,8 @@ __global__ __launch_bounds__(256, G::WPS) void conv2d_mfma_kernel(Conv2dArgs a) 
   for (int i = 0; i < NS; ++i) {
     const int r = tid + 256 * i;
     const int row = r / C, col = r - row * C;
-    const int gy = G::BANDED ? y0 + (row / TH - 1) * d + row % TH : y0 - (KS / 2) * d + row;
-    const int gx = x0 - (KS / 2) * d + col;
+    const int gy = G::BANDED ? y0 + (row / TH - 1) * d + row % TH : y0 * S - (KS / 2) * d + row;
+    const int gx = x0 * S - (KS / 2) * d + col;
     const bool ok = r < R * C && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
     sob[i] = ok ? (unsigned)(gy * a.W + gx) * 4u : 0u;
     okmask |= ok ? (1u << i) : 0u;
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(256, G::WPS) void conv2d_mfma_kernel(Conv2dArgs a) 
   };
 
   // step s = (tap, ks): 8 A fragments (2 rows x 4 M-tiles) + the tap's B vector
-  const float* abase = in_s + kq * P + (wave * RPW) * C + j;
+  const float* abase = in_s + kq * P + (wave * RPW * S) * C + j * S;
   const float* bbase = w_s + lane * VW;
   // (dq, Cq, Pq) are per-chunk opaque copies of (d, C, P): without them the compiler hoists the 9*NKS*RPW
   // tap addresses out of the channel loop and parks them in ~50 VGPRs; recomputing them is a scalar add each.
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(256, G::WPS) void conv2d_mfma_kernel(Conv2dArgs a) 
 #pragma unroll
     for (int r = 0; r < RPW; ++r)
 #pragma unroll
-      for (int xt = 0; xt < MTX; ++xt) av[r * MTX + xt] = abase[off + r * Cq + xt * 16];
+      for (int xt = 0; xt < MTX; ++xt) av[r * MTX + xt] = abase[off + r * S * Cq + xt * 16 * S];
   };
   auto load_b = [&](float (&bv)[BV], int tap) __attribute__((always_inline)) {
 #pragma unroll
@@ -206,7 +211,8 @@ __global__ __launch_bounds__(256, G::WPS) void conv2d_mfma_kernel(Conv2dArgs a) 
   }
 
   // ---- epilogue: BN scale/bias, residual, activation; lane = 4 x of one channel ----
-  const bool fast = a.fast_ok && co0 + G::COUT <= a.Cout && x0 + TW <= a.W && y0 + TH <= a.H;
+  const size_t oplane = (size_t)a.Ho * a.Wo;
+  const bool fast = a.fast_ok && co0 + G::COUT <= a.Cout && x0 + TW <= a.Wo && y0 + TH <= a.Ho;
   const float slope = a.act == DV_ACT_RELU ? 0.f : (a.act == DV_ACT_LEAKY ? 0.01f : 1.f);
   // GEN: activations that need a transcendental (Mish, sigmoid, tanh), chosen per element by a uniform switch;
   // GATED: the ConvGRU operands (mul / blend) are present
@@ -221,12 +227,12 @@ __global__ __launch_bounds__(256, G::WPS) void conv2d_mfma_kernel(Conv2dArgs a) 
       const int co = co0 + n * 16 + j;
       sc[n] = a.ch_scale ? a.ch_scale[co] : 1.f;
       bi[n] = a.ch_bias ? a.ch_bias[co] : 0.f;
-      loff[n] = (unsigned)(((size_t)co * plane + x0 + 4 * kq) * sizeof(float));
+      loff[n] = (unsigned)(((size_t)co * oplane + x0 + 4 * kq) * sizeof(float));
     }
-    const size_t bbase_o = (size_t)b * a.Cout * plane;
+    const size_t bbase_o = (size_t)b * a.Cout * oplane;
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
-      const size_t rowo = bbase_o + (size_t)(y0 + wave * RPW + r) * a.W;     // scalar
+      const size_t rowo = bbase_o + (size_t)(y0 + wave * RPW + r) * a.Wo;    // scalar
       char* orow = reinterpret_cast<char*>(a.out + rowo);
       const char* rrow = reinterpret_cast<const char*>(RES ? a.residual + rowo : nullptr);
 #pragma unroll
@@ -277,15 +283,15 @@ __global__ __launch_bounds__(256, G::WPS) void conv2d_mfma_kernel(Conv2dArgs a) 
     if (co >= a.Cout) continue;
     const float sc = a.ch_scale ? a.ch_scale[co] : 1.f;
     const float bi = a.ch_bias ? a.ch_bias[co] : 0.f;
-    const size_t cbase = ((size_t)b * a.Cout + co) * plane;
+    const size_t cbase = ((size_t)b * a.Cout + co) * oplane;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const int yo = y0 + wave * RPW + m / MTX, xo = x0 + (m % MTX) * 16 + 4 * kq;
-      if (yo >= a.H || xo >= a.W) continue;
-      const size_t o = cbase + (size_t)yo * a.W + xo;
+      if (yo >= a.Ho || xo >= a.Wo) continue;
+      const size_t o = cbase + (size_t)yo * a.Wo + xo;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (xo + e < a.W) {
+        if (xo + e < a.Wo) {
           float u = fmaf(acc[m][n][e], sc, bi);
           if (a.residual) u += a.residual[o + e];
           u = dv_act(u, a.act);
@@ -328,8 +334,8 @@ inline int kc_of(int k, int /*dil*/) { return k == 3 ? 4 : 8; }
 
 template <class G>
 int launch2d(Conv2dArgs a, hipStream_t s) {
-  a.ntx = (a.W + G::TW - 1) / G::TW;
-  a.nty = (a.H + G::TH - 1) / G::TH;
+  a.ntx = (a.Wo + G::TW - 1) / G::TW;
+  a.nty = (a.Ho + G::TH - 1) / G::TH;
   a.nco = pad_to(a.Cout, G::COUT) / G::COUT;
   const long long blocks = (long long)a.B * a.nco * a.nty * a.ntx;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return DV_ERR_SHAPE;
@@ -362,13 +368,15 @@ extern "C" int dv_conv2d_pack_weights_f32(const float* w, float* wpacked, int Ci
 
 static int conv2d_run(const float* in, const float* wpacked, const float* ch_scale, const float* ch_bias,
                       const float* residual, const float* mul, const float* blend_z, const float* blend_h, float* out,
-                      int B, int Cin, int H, int W, int Cout, int k, int dilation, int act, dv_stream_t stream) {
+                      int B, int Cin, int H, int W, int Cout, int k, int dilation, int stride, int act,
+                      dv_stream_t stream) {
   DV_REQUIRE_PTR(in);
   DV_REQUIRE_PTR(wpacked);
   DV_REQUIRE_PTR(out);
   DV_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, DV_ERR_SHAPE);
   DV_REQUIRE(k == 1 || k == 3, DV_ERR_UNSUPPORTED);
   DV_REQUIRE(k == 1 || (dilation >= 1 && dilation <= 16), DV_ERR_UNSUPPORTED);
+  DV_REQUIRE(stride == 1 || (stride == 2 && (k == 1 || dilation == 1)), DV_ERR_UNSUPPORTED);
   DV_REQUIRE(act >= DV_ACT_NONE && act <= DV_ACT_TANH, DV_ERR_UNSUPPORTED);
   DV_REQUIRE((blend_z == nullptr) == (blend_h == nullptr), DV_ERR_NULL);
   DV_REQUIRE(dv_aligned16(wpacked), DV_ERR_ALIGN);
@@ -377,13 +385,19 @@ static int conv2d_run(const float* in, const float* wpacked, const float* ch_sca
   a.in = in; a.wpk = wpacked; a.ch_scale = ch_scale; a.ch_bias = ch_bias; a.residual = residual; a.out = out;
   a.mul = mul; a.blend_z = blend_z; a.blend_h = blend_h;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.dil = k == 1 ? 0 : dilation; a.act = act;
-  a.vec_store = (W % 4 == 0) && dv_aligned16(out) && (!residual || dv_aligned16(residual)) &&
+  a.Ho = (H - 1) / stride + 1;          // 'same' padding: pad = dilation (k 3) / 0 (k 1)
+  a.Wo = (W - 1) / stride + 1;
+  a.vec_store = (a.Wo % 4 == 0) && dv_aligned16(out) && (!residual || dv_aligned16(residual)) &&
                 (!mul || dv_aligned16(mul)) && (!blend_z || (dv_aligned16(blend_z) && dv_aligned16(blend_h)));
-  a.fast_ok = a.vec_store && (size_t)Cout * H * W * sizeof(float) <= 0xffffffffull;
+  a.fast_ok = a.vec_store && (size_t)Cout * a.Ho * a.Wo * sizeof(float) <= 0xffffffffull;
   a.ntx = a.nty = a.nco = 0;
   hipStream_t s = (hipStream_t)stream;
   const int NT = nt_of(Cout);
-  //                              KS NT KC DMAX BANDED RPW [WPS]
+  //                              KS NT KC DMAX BANDED RPW [WPS MTX S]
+  if (stride == 2) {
+    if (k == 1) return NT == 2 ? launch2d<G2<1, 2, 8, 0, false, 2, 2, 4, 2>>(a, s) : launch2d<G2<1, 1, 8, 0, false, 2, 2, 4, 2>>(a, s);
+    return NT == 2 ? launch2d<G2<3, 2, 4, 1, false, 2, 2, 4, 2>>(a, s) : launch2d<G2<3, 1, 4, 1, false, 2, 3, 4, 2>>(a, s);
+  }
   if (k == 1) {
     if (NT == 2) return launch2d<G2<1, 2, 8, 0, false, 2>>(a, s);
     return launch2d<G2<1, 1, 8, 0, false, 2>>(a, s);
@@ -411,7 +425,7 @@ extern "C" int dv_conv2d_f32(const float* in, const float* wpacked, const float*
                              const float* residual, float* out, int B, int Cin, int H, int W, int Cout, int k,
                              int dilation, int act, dv_stream_t stream) {
   return conv2d_run(in, wpacked, ch_scale, ch_bias, residual, nullptr, nullptr, nullptr, out, B, Cin, H, W, Cout, k,
-                    dilation, act, stream);
+                    dilation, 1, act, stream);
 }
 
 extern "C" int dv_conv2d_gated_f32(const float* in, const float* wpacked, const float* ch_scale, const float* ch_bias,
@@ -419,5 +433,12 @@ extern "C" int dv_conv2d_gated_f32(const float* in, const float* wpacked, const 
                                    float* out, int B, int Cin, int H, int W, int Cout, int k, int dilation, int act,
                                    dv_stream_t stream) {
   return conv2d_run(in, wpacked, ch_scale, ch_bias, residual, mul, blend_z, blend_h, out, B, Cin, H, W, Cout, k,
-                    dilation, act, stream);
+                    dilation, 1, act, stream);
+}
+
+extern "C" int dv_conv2d_s2_f32(const float* in, const float* wpacked, const float* ch_scale, const float* ch_bias,
+                                const float* residual, float* out, int B, int Cin, int H, int W, int Cout, int k,
+                                int act, dv_stream_t stream) {
+  return conv2d_run(in, wpacked, ch_scale, ch_bias, residual, nullptr, nullptr, nullptr, out, B, Cin, H, W, Cout, k, 1, 2,
+                    act, stream);
 }

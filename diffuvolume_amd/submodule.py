@@ -288,14 +288,16 @@ class Conv2dPlan:
     (KITTI15/core/update.py)."""
 
     def __init__(self, weight: torch.Tensor, bn: Optional[Tuple[torch.Tensor, ...]] = None, dilation: int = 1,
-                 act: int = ACT_NONE, eps: float = 1e-5, bias: Optional[torch.Tensor] = None):
+                 act: int = ACT_NONE, eps: float = 1e-5, bias: Optional[torch.Tensor] = None, stride: int = 1):
         w = _dev_f32(weight.detach(), "weight")
         self.cout, self.cin, k = w.shape[0], w.shape[1], w.shape[2]
         if tuple(w.shape[2:]) != (k, k) or k not in (1, 3):
             raise _lib.DiffuVolumeError(f"unsupported Conv2d kernel {tuple(w.shape[2:])}")
         if k == 3 and not 1 <= dilation <= 16:
             raise _lib.DiffuVolumeError("3x3 convolutions: dilation 1..16")
-        self.k, self.dilation, self.act = k, (dilation if k == 3 else 1), act
+        if stride not in (1, 2) or (stride == 2 and k == 3 and dilation != 1):
+            raise _lib.DiffuVolumeError("stride 1, or stride 2 with dilation 1")
+        self.k, self.dilation, self.act, self.stride = k, (dilation if k == 3 else 1), act, stride
         lib = _lib.load()
         self.wpacked = torch.empty(lib.dv_conv2d_packed_floats(self.cin, self.cout, k, self.dilation),
                                    dtype=torch.float32, device=w.device)
@@ -311,7 +313,24 @@ class Conv2dPlan:
         b, cin, h, w = x.shape
         if cin != self.cin:
             raise RuntimeError(f"expected {self.cin} input channels, got {cin}")
-        out = torch.empty((b, self.cout, h, w), dtype=torch.float32, device=x.device)
+        out = torch.empty((b, self.cout, (h - 1) // self.stride + 1, (w - 1) // self.stride + 1), dtype=torch.float32,
+                          device=x.device)
+        if self.stride == 2:
+            if mul is not None or blend is not None:
+                raise RuntimeError("gate operands are stride-1 only")
+            if residual is not None:
+                residual = _dev_f32(residual, "residual")
+                if tuple(residual.shape) != tuple(out.shape):
+                    raise RuntimeError("residual shape mismatch")
+            lib = _lib.load()
+            with torch.cuda.device(x.device):
+                timed(f"conv2d_k{self.k}s2_co{self.cout}", 2.0 * out.numel() * cin * self.k ** 2,
+                      4.0 * (x.numel() + out.numel() * (1 if residual is None else 2)),
+                      lambda: _lib.check(lib.dv_conv2d_s2_f32(x.data_ptr(), self.wpacked.data_ptr(), _lib.ptr(self.scale),
+                                                              _lib.ptr(self.shift), _lib.ptr(residual), out.data_ptr(), b,
+                                                              cin, h, w, self.cout, self.k, self.act, _lib.stream_ptr()),
+                                         "dv_conv2d_s2_f32"))
+            return out
 
         def same(t, name):
             t = _dev_f32(t, name)

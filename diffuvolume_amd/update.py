@@ -27,9 +27,9 @@ class _Planned(nn.Module):
         self._plans = None
         return super()._apply(fn, *a, **k)
 
-    def load_state_dict(self, *a, **k):
+    def _load_from_state_dict(self, *a, **k):      # runs for every sub-module, also when a parent is loaded
         self._plans = None
-        return super().load_state_dict(*a, **k)
+        return super()._load_from_state_dict(*a, **k)
 
     def plans(self):
         if self._plans is None:

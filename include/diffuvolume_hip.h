@@ -140,6 +140,13 @@ int dv_conv2d_gated_f32(const float* in, const float* wpacked, const float* ch_s
                         float* out, int B, int Cin, int H, int W, int Cout, int k, int dilation, int act,
                         dv_stream_t stream);
 
+/* Stride-2 flavour (the down-sampling layers of the 2-D feature CNNs: SceneFlow/models/acv_ddim.py:19-21, :28 --
+ * convbn(k 3, stride 2, pad 1) and the 1x1 stride-2 `downsample`): out [B,Cout,(H-1)/2+1,(W-1)/2+1], dilation 1,
+ * residual (if any) has the output's shape.  Same packed weights as dv_conv2d_f32 with dilation 1. */
+int dv_conv2d_s2_f32(const float* in, const float* wpacked, const float* ch_scale, const float* ch_bias,
+                     const float* residual, float* out, int B, int Cin, int H, int W, int Cout, int k, int act,
+                     dv_stream_t stream);
+
 /* Input assembly of that refinement (KITTI12/models/pwcnet_ddim.py:486-502), fused:
  *   frw = warp(right, disp)  (models/submodule.py:137-176, incl. its align_corners mismatch and >= 0.999 mask),
  *   cv  = build_corrleation_volume(left, frw, maxshift, 1)  (:121-135, incl. its negative-shift slicing),

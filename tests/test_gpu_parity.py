@@ -575,3 +575,44 @@ def test_deconv_fused_redir(cfg):
                           redir=(dev(wr), tuple(dev(t) for t in bnr)))
     out = plan(dev(x), skip=dev(skip))
     assert out.shape == y.shape and rel_err(out, y) < 1e-5
+
+
+@pytest.mark.parametrize("cfg", [
+    # cin, cout, k, (B, H, W), act, residual
+    (3, 32, 3, (2, 32, 96), "relu", False),        # the first layer of the feature CNN (acv_ddim.py:19)
+    (32, 64, 3, (1, 17, 70), "relu", False),       # odd sizes: output (H-1)/2+1
+    (32, 64, 1, (1, 16, 130), "none", False),      # 1x1 stride-2 `downsample`
+    (64, 128, 3, (1, 24, 64), "none", True),
+])
+def test_conv2d_stride2_oracle(cfg):
+    cin, cout, k, dims, act, use_res = cfg
+    g = _gen(61, str(cfg))
+    x = torch.randn(dims[0], cin, dims[1], dims[2], generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (k * k * cin)) ** 0.5
+    bn = (torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1,
+          torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5)
+    y = torch.nn.functional.conv2d(x, w, None, 2, 1 if k == 3 else 0)
+    y = torch.nn.functional.batch_norm(y, bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5)
+    res = torch.randn(y.shape, generator=g) if use_res else None
+    if res is not None:
+        y = y + res
+    y = torch.relu(y) if act == "relu" else y
+    plan = S.Conv2dPlan(dev(w), tuple(dev(t) for t in bn), act=S.ACT_RELU if act == "relu" else S.ACT_NONE, stride=2)
+    out = plan(dev(x), residual=None if res is None else dev(res))
+    assert out.shape == y.shape and rel_err(out, y) < 1e-5
+
+
+def test_feature_cnn_on_hip_matches_the_pytorch_modules():
+    """FeatureExtraction (acv_ddim.py:14-53) through the fused 2-D kernel vs the same nn.Modules run by PyTorch."""
+    import diffuvolume_amd as dv
+    m = dv.ACVNet_DDIM(192, False, False)
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed=5), strict=True)
+    fe = m.feature_extraction.to(DEV).eval()
+    x = torch.randn(2, 3, 64, 160, generator=_gen(71, "img")).to(DEV)
+    with torch.no_grad():
+        y = fe(x)["gwc_feature"]
+        t = fe.layer1(fe.firstconv(x))
+        l2 = fe.layer2(t); l3 = fe.layer3(l2); l4 = fe.layer4(l3)
+        ref = torch.cat((l2, l3, l4), dim=1)
+    assert y.shape == ref.shape == (2, 320, 16, 40)
+    assert rel_err(y, ref.cpu()) < 2e-5

@@ -63,10 +63,16 @@ def test_time_embedding_matches_reference(model, acv_state_dict):
 
 
 def test_feature_extractor_shapes(model):
+    """The parameter containers are plain nn.Modules (1/4 resolution, 64 + 128 + 128 channels); the module's own
+    forward runs on the HIP kernels and refuses CPU tensors like the rest of the path."""
     model.eval()
+    fe = model.feature_extraction
     with torch.no_grad():
-        f = model.feature_extraction(torch.zeros(1, 3, 32, 64))["gwc_feature"]
-    assert tuple(f.shape) == (1, 320, 8, 16)
+        l2 = fe.layer2(fe.layer1(fe.firstconv(torch.zeros(1, 3, 32, 64))))
+        l4 = fe.layer4(fe.layer3(l2))
+    assert tuple(l2.shape) == (1, 64, 8, 16) and tuple(l4.shape) == (1, 128, 8, 16)
+    with pytest.raises(DiffuVolumeError):
+        fe(torch.zeros(1, 3, 32, 64))
 
 
 def test_hot_path_refuses_cpu(model):

@@ -29,7 +29,7 @@ from . import _lib
 from .head import DynamicHead
 from .submodule import (ACT_NONE, ACT_RELU, Conv2dPlan, Conv3dPlan, Deconv3dPlan, _dev_f32,
                         build_concat_attention_volume, build_gwc_volume, check_split_overflow,
-                        default_conv_precision, upsample_softmax_regress, window_attention)
+                        default_conv_precision, patch_volume, upsample_softmax_regress, window_attention)
 
 
 def any_split_plan(plans) -> bool:
@@ -242,6 +242,12 @@ class _Plans:
         self.dres1_att = _ConvPairPlan(m.dres1_att_, relu_last=False)
         self.dres2_att = _HourglassPlan(m.dres2_att_)
         self.classif_att = _ConvPairPlan(m.classif_att_, relu_last=False)
+        # attention branch front: the two depth-wise (1,3,3) stencils fuse into one pass; concatconv on the 2-D kernel
+        self.patch_w1 = m.patch.weight.detach().float().reshape(40, 9).contiguous()
+        self.patch_w2 = torch.cat([p.weight.detach().float().reshape(-1, 9) for p in (m.patch_l1, m.patch_l2, m.patch_l3)]).contiguous()
+        self.patch_dil = torch.tensor([1] * 8 + [2] * 16 + [3] * 16, dtype=torch.int32, device=self.patch_w1.device)
+        self.concat_a = _plan_cb2(m.concatconv[0], ACT_RELU)
+        self.concat_b = Conv2dPlan(m.concatconv[2].weight, None, act=ACT_NONE)
         if hasattr(m, "alphas_cumprod"):                       # the origin ACVNet has no diffusion schedule
             ac = m.alphas_cumprod.detach().double().cpu()
             self.alphas_cumprod = ac
@@ -534,13 +540,10 @@ class ACVNet_DDIM(_HipPlanMixin):
         softmax-weighted concat volume (the tensor the DDIM loop filters)."""
         p = self.prepare()
         gwc = build_gwc_volume(feat_left, feat_right, self.maxdisp // 4, self.num_groups)
-        gwc = self.patch(gwc)
-        patch_volume = torch.cat((self.patch_l1(gwc[:, :8]), self.patch_l2(gwc[:, 8:24]),
-                                  self.patch_l3(gwc[:, 24:40])), dim=1)
-        att = p.dres1_att(patch_volume)
+        att = p.dres1_att(patch_volume(gwc, p.patch_w1, p.patch_w2, p.patch_dil))     # patch, patch_l1..3 (:377-381)
         att = p.classif_att(p.dres2_att(att))
-        cl = self.concatconv(feat_left)
-        cr = self.concatconv(feat_right)
+        cl = p.concat_b(p.concat_a(feat_left))
+        cr = p.concat_b(p.concat_a(feat_right))
         return build_concat_attention_volume(cl, cr, att, self.maxdisp // 4)
 
     def forward(self, left, right, used, disp, mask_gt=None):

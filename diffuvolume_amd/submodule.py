@@ -17,7 +17,7 @@ from .profiling import timed
 
 __all__ = ["build_gwc_volume", "build_concat_volume", "build_concat_attention_volume",
            "disparity_regression", "upsample_softmax_regress", "Conv3dPlan", "Conv2dPlan", "Deconv3dPlan",
-           "window_attention", "feature_gate", "softmax_regress", "refine_inputs", "ACT_NONE", "ACT_RELU", "ACT_MISH", "ACT_LEAKY", "ACT_SIGMOID", "ACT_TANH"]
+           "window_attention", "feature_gate", "softmax_regress", "refine_inputs", "patch_volume", "ACT_NONE", "ACT_RELU", "ACT_MISH", "ACT_LEAKY", "ACT_SIGMOID", "ACT_TANH"]
 
 ACT_NONE, ACT_RELU, ACT_MISH, ACT_LEAKY, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4, 5     # last two: 2-D convs only
 
@@ -488,6 +488,24 @@ def refine_inputs(left: torch.Tensor, right: torch.Tensor, disp: torch.Tensor, d
               lambda: _lib.check(lib.dv_refine_inputs_f32(left.data_ptr(), right.data_ptr(), disp.data_ptr(),
                                                           du_a.data_ptr(), du_b.data_ptr(), out.data_ptr(), b, c, h, w,
                                                           maxshift, _lib.stream_ptr()), "dv_refine_inputs_f32"))
+    return out
+
+
+def patch_volume(gwc: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, dilation: torch.Tensor) -> torch.Tensor:
+    """`patch` followed by `patch_l1/l2/l3` (acv_ddim.py:377-381): two per-channel (1,3,3) stencils in one pass.
+    gwc [B,G,D,H,W]; w1, w2 [G,9] float32; dilation [G] int32 (1..3)."""
+    gwc = _dev_f32(gwc, "gwc")
+    b, g, d, h, w = gwc.shape
+    w1, w2 = _dev_f32(w1, "w1"), _dev_f32(w2, "w2")
+    if tuple(w1.shape) != (g, 9) or tuple(w2.shape) != (g, 9) or dilation.numel() != g or dilation.dtype != torch.int32:
+        raise RuntimeError("w1 / w2 must be [G,9] and dilation [G] int32")
+    out = torch.empty_like(gwc)
+    lib = _lib.load()
+    with torch.cuda.device(gwc.device):
+        timed("patch_volume", 36.0 * gwc.numel(), 8.0 * gwc.numel(),
+              lambda: _lib.check(lib.dv_patch_volume_f32(gwc.data_ptr(), w1.data_ptr(), w2.data_ptr(),
+                                                         dilation.contiguous().data_ptr(), out.data_ptr(), b, g, d, h, w,
+                                                         _lib.stream_ptr()), "dv_patch_volume_f32"))
     return out
 
 

@@ -173,6 +173,13 @@ int dv_deconv3d_k3s2_redir_f32(const float* in, const float* wpacked, const floa
                                const float* redir_w, float* out, int B, int Cin, int D, int H, int W, int Cout,
                                int Cskip, int act, dv_stream_t stream);
 
+/* The attention branch's depth-wise stencils on the gwc volume (SceneFlow/models/acv_ddim.py:181-188, :377-381):
+ * out = cat_g( Conv3d_(1,3,3),dil_g( Conv3d_(1,3,3)(gwc) ) ), both per channel (groups = channels), zero padded.
+ * gwc/out [B,G,D,H,W]; w1 = `patch` weights [G][9]; w2 = the matching `patch_l1/l2/l3` weights [G][9];
+ * dilation [G] (int32, 1..3).  All pointers on the device. */
+int dv_patch_volume_f32(const float* gwc, const float* w1, const float* w2, const int* dilation, float* out,
+                        int B, int G, int D, int H, int W, dv_stream_t stream);
+
 /* attention_block.forward: SceneFlow/models/submodule.py:398-429 -- 4x4x4 window
  * multi-head self-attention (heads x C/heads), qkv Linear(C,3C)+bias, softmax,
  * final 1x1x1 Conv3d(C,C)+bias.  x [B,C,D,H,W] -> out same shape.  D must be a

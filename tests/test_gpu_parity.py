@@ -616,3 +616,23 @@ def test_feature_cnn_on_hip_matches_the_pytorch_modules():
         ref = torch.cat((l2, l3, l4), dim=1)
     assert y.shape == ref.shape == (2, 320, 16, 40)
     assert rel_err(y, ref.cpu()) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(1, 40, 3, 20, 140), (2, 40, 2, 33, 50)])
+def test_patch_volume_vs_pytorch_depthwise(shape):
+    """patch + patch_l1/l2/l3 (acv_ddim.py:181-188, :377-381) fused, vs the nn.Conv3d modules themselves."""
+    from diffuvolume_amd.submodule import patch_volume
+    g = _gen(81, str(shape))
+    x = torch.randn(*shape, generator=g)
+    conv = lambda c, d: torch.nn.Conv3d(c, c, (1, 3, 3), 1, (0, d, d), d, groups=c, bias=False)
+    patch, l1, l2, l3 = conv(40, 1), conv(8, 1), conv(16, 2), conv(16, 3)
+    for m in (patch, l1, l2, l3):
+        m.weight.data = torch.randn(m.weight.shape, generator=g) * 0.4
+    with torch.no_grad():
+        y = patch(x)
+        ref = torch.cat((l1(y[:, :8]), l2(y[:, 8:24]), l3(y[:, 24:40])), dim=1)
+    w1 = patch.weight.detach().reshape(40, 9)
+    w2 = torch.cat([m.weight.detach().reshape(-1, 9) for m in (l1, l2, l3)])
+    dil = torch.tensor([1] * 8 + [2] * 16 + [3] * 16, dtype=torch.int32)
+    out = patch_volume(dev(x), dev(w1), dev(w2), dev(dil))
+    torch.testing.assert_close(out.cpu(), ref, atol=2e-5, rtol=1e-5)

@@ -11,8 +11,8 @@ Mish hourglasses, ``classif3``, the align_corners=True trilinear/softmax/regress
 uncertainty taken about the *refined* disparity, the two-hot re-encoding and the DDIM update.
 Also HIP: the per-step 2-D refinement network ``refinenet3`` (dilated 3x3 convbn +
 Mish, BasicBlocks, 1x1 downsamples) on the 2-D implicit-GEMM kernel (csrc/conv2d.hip).
-PyTorch (MIOpen / ATen): the 2-D feature CNN and the refinement's input assembly (bilinear feature
-upsampling, ``warp``, +-24 correlation, concatenation).
+The multi-scale 2-D feature CNN runs on the same 2-D kernel; PyTorch keeps the bilinear feature upsampling and the
+concatenations.
 Differences from the ACV flavour: x_T = randn, 3 steps, fill = cumulative
 q_sample(asd), thresholds dif<1 & unc<1, ensemble [0.9,0,0,0.1], Mish activations.
 """
@@ -85,7 +85,7 @@ def _head2d(cin, mid, cout):
 
 class FeatureExtraction(nn.Module, _Stacker):
     """Multi-scale 2-D feature CNN (pwcnet_ddim.py:12-128): gw1..gw4 at 1/4..1/32, concat features,
-    refinement feature.  Plain PyTorch."""
+    refinement feature.  On the GPU (eval) every convolution runs on the 2-D HIP kernel."""
 
     def __init__(self, concat_feature=False, concat_feature_channel=12):
         super().__init__()
@@ -111,7 +111,65 @@ class FeatureExtraction(nn.Module, _Stacker):
             self.concat3 = _head2d(256, 128, concat_feature_channel)
             self.concat4 = _head2d(512, 128, concat_feature_channel)
 
+    # ---- HIP plans (csrc/conv2d.hip: BN / Mish / residual fused), rebuilt when the parameters change ----
+    _plans = None
+
+    def _apply(self, fn, *a, **k):
+        self._plans = None
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._plans = None
+        return super()._load_from_state_dict(*a, **k)
+
+    def train(self, mode: bool = True):
+        self._plans = None
+        return super().train(mode)
+
+    def prepare(self):
+        if self._plans is None:
+            def head(seq):          # convbn + Mish + Conv2d 1x1
+                return (_plan_cb2(seq[0], ACT_MISH), Conv2dPlan(seq[2].weight, None, act=ACT_NONE))
+            with torch.no_grad():
+                p = {"first": [_plan_cb2(self.firstconv[i], ACT_MISH) for i in (0, 2, 4)]}
+                for n in ("layer1", "layer2", "layer3", "layer4", "layer5", "layer7", "layer9"):
+                    p[n] = [_Block2dPlan(b) for b in getattr(self, n)]
+                for n in ("gw2", "gw3", "gw4", "layer11") + (("lastconv", "concat2", "concat3", "concat4") if self.concat_feature else ()):
+                    p[n] = head(getattr(self, n))
+                p["refine"] = (_plan_cb2(self.layer_refine[0], ACT_MISH), _plan_cb2(self.layer_refine[2], ACT_MISH))
+            self._plans = p
+        return self._plans
+
     def forward(self, x):
+        if not x.is_cuda:
+            raise _lib.DiffuVolumeError(f"input is on {x.device}: the feature CNN runs on the MI355X (no CPU fallback)")
+        if self.training or (torch.is_grad_enabled() and x.requires_grad):
+            return self._forward_modules(x)
+        p = self.prepare()
+        def run(plans, t):
+            for q in plans:
+                t = q(t)
+            return t
+        with torch.no_grad():
+            for q in p["first"]:
+                x = q(x)
+            x = run(p["layer1"], x)
+            l2 = run(p["layer2"], x)
+            l3 = run(p["layer3"], l2)
+            l4 = run(p["layer4"], l3)
+            l5 = run(p["layer5"], l4)
+            l6 = run(p["layer7"], l5)
+            l7 = run(p["layer9"], l6)
+            fc = torch.cat((l2, l3, l4), dim=1)
+            out = {"gw1": run(p["layer11"], fc), "gw2": run(p["gw2"], l5), "gw3": run(p["gw3"], l6), "gw4": run(p["gw4"], l7)}
+            if self.concat_feature:
+                out.update(concat_feature1=run(p["lastconv"], fc), finetune_feature=run(p["refine"], fc),
+                           concat_feature2=run(p["concat2"], l5), concat_feature3=run(p["concat3"], l6),
+                           concat_feature4=run(p["concat4"], l7))
+        return out
+
+    def _forward_modules(self, x):
+        """The same graph on the plain nn.Modules (training / autograd on the GPU; reference for the tests)."""
         x = self.layer1(self.firstconv(x))
         l2 = self.layer2(x)
         l3 = self.layer3(l2)
@@ -264,7 +322,7 @@ class _PairPlan:
 def _plan_cb2(seq, act):
     """convbn 2-D (Conv2d + BatchNorm2d, submodule.py:21-24) -> fused plan."""
     conv, bn = seq[0], seq[1]
-    return Conv2dPlan(conv.weight, _bn_of(bn), dilation=conv.dilation[0], act=act, eps=bn.eps)
+    return Conv2dPlan(conv.weight, _bn_of(bn), dilation=conv.dilation[0], act=act, eps=bn.eps, stride=conv.stride[0])
 
 
 class _Block2dPlan:

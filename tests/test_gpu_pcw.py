@@ -140,3 +140,15 @@ def test_refine_inputs_vs_torch_composition(shape):
     out = refine_inputs(dev(fl), dev(fr), dev(p3), dev(du_a), dev(du_b), 24)
     assert out.shape == ref.shape
     torch.testing.assert_close(out.cpu(), ref, atol=2e-5, rtol=1e-5)
+
+
+def test_feature_cnn_on_hip_matches_the_pytorch_modules(model):
+    """The multi-scale feature CNN (pwcnet_ddim.py:12-128) on the fused 2-D kernel vs the same nn.Modules in PyTorch."""
+    fe = model.feature_extraction
+    x = torch.randn(1, 3, 64, 160, generator=_gen(91, "img")).to(DEV) * 0.05
+    with torch.no_grad():
+        got, ref = fe(x), fe._forward_modules(x)
+    assert set(got) == set(ref)
+    for k in ref:
+        assert got[k].shape == ref[k].shape
+        assert rel_err(got[k], ref[k].cpu()) < 5e-5, k

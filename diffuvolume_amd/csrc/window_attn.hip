@@ -2,7 +2,7 @@
 // Replaces attention_block.forward (SceneFlow/models/submodule.py:398-429): the view/permute
 // copies, qkv Linear(128,384)+bias, per-head softmax(q k^T / sqrt(8)) v, the head merge and
 // the final 1x1x1 Conv3d(128,128)+bias become ONE kernel, one workgroup per window, with the
-// window's 64 tokens x 128 channels resident in LDS from the first load to the last store.
+// window's 64 tokens x 128 channels resident on chip (registers + LDS) from the first load to the last store.
 //
 // Token order inside a window is the reference's (permute 0,2,4,6,3,5,7,1): tok = ld*16+lh*4+lw.
 // qkv feature f = which*128 + head*8 + dim; merged channel = head*8 + dim.
@@ -15,13 +15,8 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int C = 128, HEADS = 16, HD = 8, TOK = 64;
-constexpr int LDX = 80;    // X_s[c][tok]   stride == 16 (mod 32): the 4 k-lanes hit disjoint banks
 constexpr int LDW = 130;   // W_s[n][k]     stride == 2 (mod 32): banks 2j+kq are distinct
 constexpr int LDO = 130;   // O_s[tok][c]
-constexpr int LDQ = 100;   // Q_s[tok][96]  (q|k|v of 4 heads); 4*LDQ == 16 (mod 32)
-constexpr int GH = 4;      // heads per group
-constexpr int GF = 3 * GH * HD;  // 96 features per group
-constexpr int X_FLOATS = C * LDX, O_FLOATS = TOK * LDO, W_FLOATS = GF * LDW, Q_FLOATS = TOK * LDQ;
 
 struct AttnArgs {
   const float* x;
@@ -45,12 +40,28 @@ __device__ __forceinline__ void stage_rows(float* w_s, int dst_row, const float*
   }
 }
 
-__global__ __launch_bounds__(256) void window_attn_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[X_FLOATS + O_FLOATS + W_FLOATS + Q_FLOATS];
-  float* x_s = smem;
-  float* o_s = x_s + X_FLOATS;
-  float* w_s = o_s + O_FLOATS;
-  float* q_s = w_s + W_FLOATS;
+// Layout for two blocks per CU (72 KB of LDS; a first version kept the window, 4 heads of q|k|v, 96 weight rows and
+// the outputs in 150 KB and ran one block per CU at 1.02 ms -- this one takes 0.63 ms): the window's activations
+// live in registers as the A fragments of the qkv GEMM (32 per lane), heads are processed two at a time (48 weight
+// rows, 13 KB of q|k|v), and all four waves work on the 2 x 64 x 64 attention: wave = (head, key half), the two
+// halves merged with the running-max rule.  Two resident blocks overlap each other's staging, MFMA and vector
+// phases.
+namespace v2 {
+constexpr int GH2 = 2, GF2 = 3 * GH2 * HD;      // 48 features per group
+constexpr int LDQ2 = 52;                        // 4*LDQ2 == 16 (mod 32)
+constexpr int WROWS = 48;                       // weight rows resident at a time (also >= 32 for the projection)
+constexpr int PSTRIDE = 12;                     // partial record: m, s, o[8] (+pad)
+constexpr int O2 = TOK * LDO, W2 = WROWS * LDW, Q2 = TOK * LDQ2;
+static_assert(2 * 2 * TOK * PSTRIDE <= W2, "partials reuse the weight region");
+static_assert((O2 + W2 + Q2) * 4 <= 80 * 1024, "two blocks per CU");
+}  // namespace v2
+
+__global__ __launch_bounds__(256, 2) void window_attn_kernel(AttnArgs a) {
+  using namespace v2;
+  __shared__ __attribute__((aligned(16))) float smem[O2 + W2 + Q2];
+  float* o_s = smem;
+  float* w_s = o_s + O2;
+  float* q_s = w_s + W2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kq = lane >> 4;
 
@@ -62,73 +73,55 @@ __global__ __launch_bounds__(256) void window_attn_kernel(AttnArgs a) {
   const int d0 = wd * 4, h0 = wh * 4, w0 = ww * 4;
   const size_t plane = (size_t)a.H * a.W, vol = (size_t)a.D * plane;
   const float* xb = a.x + (size_t)b * C * vol;
-  const bool vec = (a.W % 4 == 0) && ((((uintptr_t)a.x) & 15u) == 0);
 
-  // ---- load the window: x_s[c][tok], zero for padded tokens ----
-  for (int e = tid; e < C * 16; e += 256) {
-    const int c = e >> 4, row = e & 15, ld = row >> 2, lh = row & 3;
-    const int gy = h0 + lh;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (gy < a.H) {
-      const float* src = xb + (size_t)c * vol + (size_t)(d0 + ld) * plane + (size_t)gy * a.W + w0;
-      if (vec) {
-        const float4 q = *reinterpret_cast<const float4*>(src);
-        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-      } else {
-        for (int i = 0; i < 4; ++i)
-          if (w0 + i < a.W) v[i] = src[i];
-      }
-    }
-    *reinterpret_cast<float4*>(x_s + c * LDX + row * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  // A fragments of this wave's 16 tokens (ld = wave, lh = j >> 2, lw = j & 3): channel ks*4 + kq
+  float xa[C / 4];
+  {
+    const int gy = h0 + (j >> 2), gx = w0 + (j & 3);
+    const bool in = gy < a.H && gx < a.W;
+    const float* src = xb + (size_t)(d0 + wave) * plane + (size_t)(in ? gy : 0) * a.W + (in ? gx : 0) + (size_t)kq * vol;
+#pragma unroll
+    for (int ks = 0; ks < C / 4; ++ks) xa[ks] = in ? src[(size_t)ks * 4 * vol] : 0.f;
   }
-
-  // per-token pad flag of this lane's query (only used when mask_on)
-  const int q_ld = lane >> 4, q_lh = (lane >> 2) & 3, q_lw = lane & 3;
-  (void)q_ld;
+  const int q_lh = (lane >> 2) & 3, q_lw = lane & 3;
   const bool q_pad = a.mask_on && ((h0 + q_lh >= a.H) || (w0 + q_lw >= a.W));
 
-  for (int g = 0; g < HEADS / GH; ++g) {
-    __syncthreads();  // x_s ready / previous group done with w_s, q_s
-    // ---- stage the q|k|v weight rows of heads [4g, 4g+4) ----
+  for (int g = 0; g < HEADS / GH2; ++g) {
+    __syncthreads();                                   // previous group's partials / q_s are consumed
     for (int which = 0; which < 3; ++which)
-      stage_rows(w_s, which * GH * HD, a.qkv_w + (size_t)(which * C + g * GH * HD) * C, GH * HD, tid);
+      stage_rows(w_s, which * GH2 * HD, a.qkv_w + (size_t)(which * C + g * GH2 * HD) * C, GH2 * HD, tid);
     __syncthreads();
-    // ---- GEMM1: q_s[tok][f] = x[tok][:] . Wg[f][:] + b   (wave = 16-token tile) ----
-    {
-      f32x4 acc[GF / 16];
+    {   // GEMM1: q_s[tok][f] = x[tok][:] . Wg[f][:] + b
+      f32x4 acc[GF2 / 16];
 #pragma unroll
-      for (int n = 0; n < GF / 16; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const float* ap = x_s + kq * LDX + wave * 16 + j;
+      for (int n = 0; n < GF2 / 16; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const float* bp = w_s + j * LDW + kq;
-#pragma unroll 4
-      for (int ks = 0; ks < C / 4; ++ks) {
-        const float av = ap[ks * 4 * LDX];
 #pragma unroll
-        for (int n = 0; n < GF / 16; ++n)
-          acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bp[n * 16 * LDW + ks * 4], acc[n], 0, 0, 0);
-      }
+      for (int ks = 0; ks < C / 4; ++ks)
 #pragma unroll
-      for (int n = 0; n < GF / 16; ++n) {
-        const int f = n * 16 + j;                         // feature within the group block
-        const int which = f / (GH * HD), hf = f % (GH * HD);
-        const float bias = a.qkv_b[which * C + g * GH * HD + hf];
+        for (int n = 0; n < GF2 / 16; ++n)
+          acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks], bp[n * 16 * LDW + ks * 4], acc[n], 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) q_s[(wave * 16 + 4 * kq + r) * LDQ + f] = acc[n][r] + bias;
+      for (int n = 0; n < GF2 / 16; ++n) {
+        const int f = n * 16 + j;                       // which = n, feature within the 2-head block = j
+        const float bias = a.qkv_b[n * C + g * GH2 * HD + j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q_s[(wave * 16 + 4 * kq + r) * LDQ2 + f] = acc[n][r] + bias;
       }
     }
     __syncthreads();
-    // ---- attention of head 4g+wave: lane = query token ----
-    {
-      const int hoff = wave * HD;
-      const float4 qa = *reinterpret_cast<const float4*>(q_s + lane * LDQ + hoff);
-      const float4 qb = *reinterpret_cast<const float4*>(q_s + lane * LDQ + hoff + 4);
+    {   // attention: wave = (head, key half), lane = query
+      const int head = wave >> 1, kh = wave & 1, hoff = head * HD;
+      const float4 qa = *reinterpret_cast<const float4*>(q_s + lane * LDQ2 + hoff);
+      const float4 qb = *reinterpret_cast<const float4*>(q_s + lane * LDQ2 + hoff + 4);
       const float scale = 0.35355339059327379f;  // 8^-0.5
-      float sc[TOK];
+      float sc[TOK / 2];
       float mx = -INFINITY;
 #pragma unroll
-      for (int k = 0; k < TOK; ++k) {
-        const float4 ka = *reinterpret_cast<const float4*>(q_s + k * LDQ + GH * HD + hoff);
-        const float4 kb = *reinterpret_cast<const float4*>(q_s + k * LDQ + GH * HD + hoff + 4);
+      for (int kk = 0; kk < TOK / 2; ++kk) {
+        const int k = kh * (TOK / 2) + kk;
+        const float4 ka = *reinterpret_cast<const float4*>(q_s + k * LDQ2 + GH2 * HD + hoff);
+        const float4 kb = *reinterpret_cast<const float4*>(q_s + k * LDQ2 + GH2 * HD + hoff + 4);
         float s = qa.x * ka.x;
         s = fmaf(qa.y, ka.y, s); s = fmaf(qa.z, ka.z, s); s = fmaf(qa.w, ka.w, s);
         s = fmaf(qb.x, kb.x, s); s = fmaf(qb.y, kb.y, s); s = fmaf(qb.z, kb.z, s); s = fmaf(qb.w, kb.w, s);
@@ -137,57 +130,68 @@ __global__ __launch_bounds__(256) void window_attn_kernel(AttnArgs a) {
           const bool k_pad = (h0 + ((k >> 2) & 3) >= a.H) || (w0 + (k & 3) >= a.W);
           if (k_pad != q_pad) s += -1000.0f;
         }
-        sc[k] = s;
+        sc[kk] = s;
         mx = fmaxf(mx, s);
       }
       float sum = 0.f;
-#pragma unroll
-      for (int k = 0; k < TOK; ++k) {
-        sc[k] = expf(sc[k] - mx);
-        sum += sc[k];
-      }
       float o[HD] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < TOK; ++k) {
-        const float p = sc[k] / sum;
-        const float4 va = *reinterpret_cast<const float4*>(q_s + k * LDQ + 2 * GH * HD + hoff);
-        const float4 vb = *reinterpret_cast<const float4*>(q_s + k * LDQ + 2 * GH * HD + hoff + 4);
+      for (int kk = 0; kk < TOK / 2; ++kk) {
+        const int k = kh * (TOK / 2) + kk;
+        const float p = expf(sc[kk] - mx);
+        sum += p;
+        const float4 va = *reinterpret_cast<const float4*>(q_s + k * LDQ2 + 2 * GH2 * HD + hoff);
+        const float4 vb = *reinterpret_cast<const float4*>(q_s + k * LDQ2 + 2 * GH2 * HD + hoff + 4);
         o[0] = fmaf(p, va.x, o[0]); o[1] = fmaf(p, va.y, o[1]); o[2] = fmaf(p, va.z, o[2]); o[3] = fmaf(p, va.w, o[3]);
         o[4] = fmaf(p, vb.x, o[4]); o[5] = fmaf(p, vb.y, o[5]); o[6] = fmaf(p, vb.z, o[6]); o[7] = fmaf(p, vb.w, o[7]);
       }
-      float2* dst = reinterpret_cast<float2*>(o_s + lane * LDO + (g * GH + wave) * HD);
-      dst[0] = make_float2(o[0], o[1]); dst[1] = make_float2(o[2], o[3]);
-      dst[2] = make_float2(o[4], o[5]); dst[3] = make_float2(o[6], o[7]);
+      // partial record of (head, key half, query) in the (now idle) weight region
+      float* pr = w_s + ((head * 2 + kh) * TOK + lane) * PSTRIDE;
+      pr[0] = mx; pr[1] = sum;
+#pragma unroll
+      for (int i = 0; i < HD; ++i) pr[2 + i] = o[i];
+    }
+    __syncthreads();
+    {   // merge the two key halves: thread = (head, query, 4 of the 8 dims)
+      const int head = tid >> 7, q = (tid & 127) >> 1, hd = (tid & 1) * 4;
+      const float* p0 = w_s + ((head * 2 + 0) * TOK + q) * PSTRIDE;
+      const float* p1 = w_s + ((head * 2 + 1) * TOK + q) * PSTRIDE;
+      const float m = fmaxf(p0[0], p1[0]);
+      const float e0 = expf(p0[0] - m), e1 = expf(p1[0] - m);
+      const float inv = 1.f / (p0[1] * e0 + p1[1] * e1);
+      float* dst = o_s + q * LDO + (g * GH2 + head) * HD + hd;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dst[i] = (p0[2 + hd + i] * e0 + p1[2 + hd + i] * e1) * inv;
     }
   }
 
-  // ---- final 1x1x1 conv: out[tok][co] = o[tok][:] . Wp[co][:] + b, 64 output channels per pass ----
+  // ---- final 1x1x1 conv, 32 output channels per pass ----
   const size_t ob = (size_t)b * C * vol;
-  for (int half = 0; half < 2; ++half) {
+  const bool vec = (a.W % 4 == 0) && ((((uintptr_t)a.out) & 15u) == 0);
+  for (int pass = 0; pass < 4; ++pass) {
     __syncthreads();
-    stage_rows(w_s, 0, a.proj_w + (size_t)half * 64 * C, 64, tid);
+    stage_rows(w_s, 0, a.proj_w + (size_t)pass * 32 * C, 32, tid);
     __syncthreads();
-    f32x4 acc[4];
+    f32x4 acc[2];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < 2; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* ap = o_s + (wave * 16 + j) * LDO + kq;
     const float* bp = w_s + j * LDW + kq;
-#pragma unroll 4
+#pragma unroll 8
     for (int ks = 0; ks < C / 4; ++ks) {
       const float av = ap[ks * 4];
 #pragma unroll
-      for (int n = 0; n < 4; ++n)
+      for (int n = 0; n < 2; ++n)
         acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bp[n * 16 * LDW + ks * 4], acc[n], 0, 0, 0);
     }
-    // lane holds tokens (ld = wave, lh = kq, lw = 0..3) of channel co
     const int gy = h0 + kq;
     if (gy < a.H) {
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        const int co = half * 64 + n * 16 + j;
+      for (int n = 0; n < 2; ++n) {
+        const int co = pass * 32 + n * 16 + j;
         const float bias = a.proj_b[co];
         float* dst = a.out + ob + (size_t)co * vol + (size_t)(d0 + wave) * plane + (size_t)gy * a.W + w0;
-        if (vec && ((((uintptr_t)a.out) & 15u) == 0)) {
+        if (vec) {
           *reinterpret_cast<float4*>(dst) =
               make_float4(acc[n][0] + bias, acc[n][1] + bias, acc[n][2] + bias, acc[n][3] + bias);
         } else {

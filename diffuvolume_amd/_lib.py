@@ -53,6 +53,7 @@ SIGNATURES = {
     "dv_conv2d_pack_weights_f32": (c_int, [P, P, I, I, I, I, P]),
     "dv_conv2d_f32": (c_int, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "dv_conv2d_gated_f32": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "dv_conv2d_cat_f32": (c_int, [P, P, I, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "dv_conv2d_s2_f32": (c_int, [P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "dv_refine_inputs_f32": (c_int, [P, P, P, P, P, P, I, I, I, I, I, P]),
     "dv_softmax_regress_f32": (c_int, [P, P, I, I, I, I, P]),

@@ -53,7 +53,9 @@ struct G2 {
 };
 
 struct Conv2dArgs {
-  const float* in;        // [B,Cin,H,W]
+  const float* in;        // [B,Cin,H,W] (first source)
+  const float* in_more[3];  // further sources of a virtual torch.cat along channels, or null
+  int cend[4];            // cumulative channel count after each source (cend[nsrc-1] == Cin)
   const float* wpk;       // see pack_conv2d_weights_kernel
   const float* ch_scale;  // [Cout] or null
   const float* ch_bias;   // [Cout] or null
@@ -98,7 +100,12 @@ __global__ __launch_bounds__(256, G::WPS) void conv2d_mfma_kernel(Conv2dArgs a) 
     for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const size_t plane = (size_t)a.H * a.W;
-  const float* inb = a.in + (size_t)b * a.Cin * plane;
+  // sources of the (virtual) channel concatenation: batch-item base pointer and first channel of each
+  const float* sb[4];
+  sb[0] = a.in + (size_t)b * a.cend[0] * plane;
+#pragma unroll
+  for (int k = 1; k < 4; ++k)
+    sb[k] = a.in_more[k - 1] ? a.in_more[k - 1] + (size_t)b * (a.cend[k] - a.cend[k - 1]) * plane : a.in;
 
   // ---- staging plan: each thread owns NS positions of the staged rows (same for every channel) ----
   constexpr int NS = (G::RMAX * G::CMAX + 255) / 256;
@@ -122,7 +129,11 @@ __global__ __launch_bounds__(256, G::WPS) void conv2d_mfma_kernel(Conv2dArgs a) 
 #pragma unroll
     for (int cl = 0; cl < KC; ++cl) {
       const int ch = c * KC + cl;
-      const char* src = reinterpret_cast<const char*>(inb + (size_t)(ch < a.Cin ? ch : 0) * plane);
+      const int cc = ch < a.Cin ? ch : 0;                                   // wave-uniform source selection
+      const int k = (cc >= a.cend[0]) + (cc >= a.cend[1]) + (cc >= a.cend[2]);
+      const float* base = k == 0 ? sb[0] : (k == 1 ? sb[1] : (k == 2 ? sb[2] : sb[3]));
+      const int c_in_src = cc - (k == 0 ? 0 : a.cend[k - 1]);
+      const char* src = reinterpret_cast<const char*>(base + (size_t)c_in_src * plane);
 #pragma unroll
       for (int i = 0; i < NS; ++i) vin[cl][i] = *reinterpret_cast<const float*>(src + sob[i]);
     }
@@ -366,7 +377,8 @@ extern "C" int dv_conv2d_pack_weights_f32(const float* w, float* wpacked, int Ci
   return dv_launch_status();
 }
 
-static int conv2d_run(const float* in, const float* wpacked, const float* ch_scale, const float* ch_bias,
+static int conv2d_run(const float* in, const float* const* more, const int* more_channels, int n_more,
+                      const float* wpacked, const float* ch_scale, const float* ch_bias,
                       const float* residual, const float* mul, const float* blend_z, const float* blend_h, float* out,
                       int B, int Cin, int H, int W, int Cout, int k, int dilation, int stride, int act,
                       dv_stream_t stream) {
@@ -382,7 +394,20 @@ static int conv2d_run(const float* in, const float* wpacked, const float* ch_sca
   DV_REQUIRE(dv_aligned16(wpacked), DV_ERR_ALIGN);
   DV_REQUIRE((size_t)H * W * sizeof(float) <= 0xffffffffull, DV_ERR_SHAPE);
   Conv2dArgs a;
-  a.in = in; a.wpk = wpacked; a.ch_scale = ch_scale; a.ch_bias = ch_bias; a.residual = residual; a.out = out;
+  a.in = in;
+  {   // Cin counts all sources; the first one owns what the others do not
+    int rest = 0;
+    for (int i = 0; i < n_more; ++i) rest += more_channels[i];
+    DV_REQUIRE(n_more >= 0 && n_more <= 3 && rest < Cin, DV_ERR_SHAPE);
+    a.cend[0] = Cin - rest;
+    for (int i = 0; i < 3; ++i) {
+      a.in_more[i] = i < n_more ? more[i] : nullptr;
+      a.cend[i + 1] = a.cend[i] + (i < n_more ? more_channels[i] : 0);
+      if (i < n_more) { DV_REQUIRE_PTR(more[i]); DV_REQUIRE(more_channels[i] > 0, DV_ERR_SHAPE); }
+    }
+    if (n_more < 3) for (int i = n_more + 1; i < 4; ++i) a.cend[i] = Cin;
+  }
+  a.wpk = wpacked; a.ch_scale = ch_scale; a.ch_bias = ch_bias; a.residual = residual; a.out = out;
   a.mul = mul; a.blend_z = blend_z; a.blend_h = blend_h;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.dil = k == 1 ? 0 : dilation; a.act = act;
   a.Ho = (H - 1) / stride + 1;          // 'same' padding: pad = dilation (k 3) / 0 (k 1)
@@ -424,21 +449,37 @@ static int conv2d_run(const float* in, const float* wpacked, const float* ch_sca
 extern "C" int dv_conv2d_f32(const float* in, const float* wpacked, const float* ch_scale, const float* ch_bias,
                              const float* residual, float* out, int B, int Cin, int H, int W, int Cout, int k,
                              int dilation, int act, dv_stream_t stream) {
-  return conv2d_run(in, wpacked, ch_scale, ch_bias, residual, nullptr, nullptr, nullptr, out, B, Cin, H, W, Cout, k,
-                    dilation, 1, act, stream);
+  return conv2d_run(in, nullptr, nullptr, 0, wpacked, ch_scale, ch_bias, residual, nullptr, nullptr, nullptr, out, B, Cin, H,
+                    W, Cout, k, dilation, 1, act, stream);
 }
 
 extern "C" int dv_conv2d_gated_f32(const float* in, const float* wpacked, const float* ch_scale, const float* ch_bias,
                                    const float* residual, const float* mul, const float* blend_z, const float* blend_h,
                                    float* out, int B, int Cin, int H, int W, int Cout, int k, int dilation, int act,
                                    dv_stream_t stream) {
-  return conv2d_run(in, wpacked, ch_scale, ch_bias, residual, mul, blend_z, blend_h, out, B, Cin, H, W, Cout, k,
-                    dilation, 1, act, stream);
+  return conv2d_run(in, nullptr, nullptr, 0, wpacked, ch_scale, ch_bias, residual, mul, blend_z, blend_h, out, B, Cin, H, W,
+                    Cout, k, dilation, 1, act, stream);
 }
 
 extern "C" int dv_conv2d_s2_f32(const float* in, const float* wpacked, const float* ch_scale, const float* ch_bias,
                                 const float* residual, float* out, int B, int Cin, int H, int W, int Cout, int k,
                                 int act, dv_stream_t stream) {
-  return conv2d_run(in, wpacked, ch_scale, ch_bias, residual, nullptr, nullptr, nullptr, out, B, Cin, H, W, Cout, k, 1, 2,
-                    act, stream);
+  return conv2d_run(in, nullptr, nullptr, 0, wpacked, ch_scale, ch_bias, residual, nullptr, nullptr, nullptr, out, B, Cin, H,
+                    W, Cout, k, 1, 2, act, stream);
+}
+
+extern "C" int dv_conv2d_cat_f32(const float* const* inputs, const int* channels, int n_inputs, const float* wpacked,
+                                 const float* ch_scale, const float* ch_bias, const float* residual, const float* mul,
+                                 const float* blend_z, const float* blend_h, float* out, int B, int H, int W, int Cout,
+                                 int k, int dilation, int act, dv_stream_t stream) {
+  DV_REQUIRE_PTR(inputs);
+  DV_REQUIRE_PTR(channels);
+  DV_REQUIRE(n_inputs >= 1 && n_inputs <= 4, DV_ERR_UNSUPPORTED);
+  int cin = 0;
+  for (int i = 0; i < n_inputs; ++i) {
+    DV_REQUIRE(channels[i] > 0, DV_ERR_SHAPE);
+    cin += channels[i];
+  }
+  return conv2d_run(inputs[0], inputs + 1, channels + 1, n_inputs - 1, wpacked, ch_scale, ch_bias, residual, mul, blend_z,
+                    blend_h, out, B, cin, H, W, Cout, k, dilation, 1, act, stream);
 }

@@ -308,9 +308,22 @@ class Conv2dPlan:
 
     def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, mul: Optional[torch.Tensor] = None,
                  blend: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
-        """act(conv(x)*scale + shift + residual) [* mul] [-> h + z*(. - h) for blend = (z, h)]."""
-        x = _dev_f32(x, "x")
-        b, cin, h, w = x.shape
+        """act(conv(x)*scale + shift + residual) [* mul] [-> h + z*(. - h) for blend = (z, h)].
+        ``x`` may be a list of up to four tensors: the convolution then runs over their channel concatenation
+        without materialising it (stride 1)."""
+        parts = None
+        if isinstance(x, (list, tuple)):
+            parts = [_dev_f32(t, "x") for t in x]
+            if not 1 <= len(parts) <= 4 or any(t.shape[0] != parts[0].shape[0] or t.shape[2:] != parts[0].shape[2:] for t in parts):
+                raise RuntimeError("virtual concatenation: 1..4 tensors with equal batch and spatial size")
+            if self.stride != 1:
+                raise RuntimeError("virtual concatenation is stride-1 only")
+            x = parts[0]
+            b, _, h, w = x.shape
+            cin = sum(t.shape[1] for t in parts)
+        else:
+            x = _dev_f32(x, "x")
+            b, cin, h, w = x.shape
         if cin != self.cin:
             raise RuntimeError(f"expected {self.cin} input channels, got {cin}")
         out = torch.empty((b, self.cout, (h - 1) // self.stride + 1, (w - 1) // self.stride + 1), dtype=torch.float32,
@@ -343,6 +356,19 @@ class Conv2dPlan:
         bz, bh = (None, None) if blend is None else (same(blend[0], "blend z"), same(blend[1], "blend h"))
         extra = sum(t is not None for t in (residual, mul, bz, bh))
         lib = _lib.load()
+        if parts is not None:
+            import ctypes
+            ptrs = (ctypes.c_void_p * len(parts))(*[t.data_ptr() for t in parts])
+            chans = (ctypes.c_int * len(parts))(*[t.shape[1] for t in parts])
+            with torch.cuda.device(x.device):
+                nb = 4.0 * (sum(t.numel() for t in parts) + out.numel() * (1 + extra))
+                timed(f"conv2d_k{self.k}d{self.dilation}_co{self.cout}", 2.0 * out.numel() * cin * self.k ** 2, nb,
+                      lambda: _lib.check(lib.dv_conv2d_cat_f32(ptrs, chans, len(parts), self.wpacked.data_ptr(),
+                                                               _lib.ptr(self.scale), _lib.ptr(self.shift), _lib.ptr(residual),
+                                                               _lib.ptr(mul), _lib.ptr(bz), _lib.ptr(bh), out.data_ptr(), b, h, w,
+                                                               self.cout, self.k, self.dilation, self.act, _lib.stream_ptr()),
+                                         "dv_conv2d_cat_f32"))
+            return out
         with torch.cuda.device(x.device):
             nb = 4.0 * (x.numel() + out.numel() * (1 + extra))
             timed(f"conv2d_k{self.k}d{self.dilation}_co{self.cout}", 2.0 * out.numel() * cin * self.k ** 2, nb,

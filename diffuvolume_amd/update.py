@@ -4,8 +4,8 @@ convention, so ``IGEVDiffusionLoop`` (or the reference's own ``ddim_sample``) ca
 
 On HIP (csrc/conv2d.hip): every 3x3 / 1x1 convolution with its bias and ReLU / sigmoid / tanh, and the ConvGRU gate
 arithmetic in the epilogues -- ``convr`` emits ``r*h`` directly, ``convq`` emits ``(1-z)*h + z*tanh(.)`` -- so a
-ConvGRU is three launches plus the two input concatenations.  PyTorch: the 7x7 single-channel ``convd1`` (0.2 GFLOP),
-``torch.cat``, average pooling and bilinear interpolation between the three scales.
+ConvGRU is three launches; the convolutions read ``[h | x...]`` as a virtual concatenation (``dv_conv2d_cat_f32``).  PyTorch: the 7x7 single-channel ``convd1`` (0.2 GFLOP),
+the motion encoder's two small ``torch.cat``, average pooling and bilinear interpolation between the three scales.
 """
 from __future__ import annotations
 
@@ -74,11 +74,12 @@ class ConvGRU(_Planned):
 
     def forward(self, h, cz, cr, cq, *x_list):
         pz, pr, pq = self.plans()
-        x = torch.cat(x_list, dim=1)
-        hx = torch.cat([h, x], dim=1)
+        if len(x_list) > 3:                             # the kernel takes four sources: [h | x1 | x2 | x3]
+            x_list = (torch.cat(x_list[:-2], dim=1),) + tuple(x_list[-2:])
+        hx = [h, *x_list]                               # torch.cat([h, x]) is never materialised
         z = pz(hx, residual=cz)                         # sigmoid(convz(hx) + cz)
         rh = pr(hx, residual=cr, mul=h)                 # sigmoid(convr(hx) + cr) * h
-        return pq(torch.cat([rh, x], dim=1), residual=cq, blend=(z, h))     # (1-z)*h + z*tanh(convq(.) + cq)
+        return pq([rh, *x_list], residual=cq, blend=(z, h))                 # (1-z)*h + z*tanh(convq(.) + cq)
 
 
 class BasicMotionEncoder(_Planned):

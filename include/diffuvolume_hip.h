@@ -140,6 +140,15 @@ int dv_conv2d_gated_f32(const float* in, const float* wpacked, const float* ch_s
                         float* out, int B, int Cin, int H, int W, int Cout, int k, int dilation, int act,
                         dv_stream_t stream);
 
+/* The gated convolution over a VIRTUAL channel concatenation: `conv(torch.cat(inputs, dim=1))` without the copy
+ * (ConvGRU.forward, KITTI15/core/update.py:33-38: hx = cat[h, x...], cat[r*h, x...]).  `inputs` / `channels` are HOST
+ * arrays of n_inputs (1..4) device pointers [B,channels[i],H,W] and their channel counts; the weights are those
+ * of the full convolution (Cin = sum of channels), packed as usual. */
+int dv_conv2d_cat_f32(const float* const* inputs, const int* channels, int n_inputs, const float* wpacked,
+                      const float* ch_scale, const float* ch_bias, const float* residual, const float* mul,
+                      const float* blend_z, const float* blend_h, float* out, int B, int H, int W, int Cout,
+                      int k, int dilation, int act, dv_stream_t stream);
+
 /* Stride-2 flavour (the down-sampling layers of the 2-D feature CNNs: SceneFlow/models/acv_ddim.py:19-21, :28 --
  * convbn(k 3, stride 2, pad 1) and the 1x1 stride-2 `downsample`): out [B,Cout,(H-1)/2+1,(W-1)/2+1], dilation 1,
  * residual (if any) has the output's shape.  Same packed weights as dv_conv2d_f32 with dilation 1. */

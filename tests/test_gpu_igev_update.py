@@ -118,3 +118,15 @@ def test_ddim_loop_with_the_real_update_block():
                              None, noise=NoiseTape(135))
     d = (final.cpu() - final_ref).abs()
     assert float(d.median()) < 2e-3 and float(d.mean()) < 5e-2, (float(d.median()), float(d.mean()))
+
+
+def test_conv2d_over_virtual_concatenation():
+    """conv(torch.cat([a, b, c], 1)) without the copy; chunk boundaries fall inside sources (20 + 6 + 38 channels)."""
+    g = _gen(151, "cat")
+    parts = [torch.randn(2, c, 9, 70, generator=g) for c in (20, 6, 38)]
+    w = torch.randn(32, 64, 3, 3, generator=g) * 0.05
+    bias = torch.randn(32, generator=g) * 0.1
+    ref = torch.relu(torch.nn.functional.conv2d(torch.cat(parts, 1), w, bias, 1, 1))
+    plan = S.Conv2dPlan(dev(w), None, act=S.ACT_RELU, bias=dev(bias))
+    torch.testing.assert_close(plan([dev(t) for t in parts]).cpu(), ref, atol=2e-6, rtol=1e-5)
+    torch.testing.assert_close(plan(dev(torch.cat(parts, 1))).cpu(), ref, atol=2e-6, rtol=1e-5)

@@ -529,6 +529,7 @@ extern "C" int dv_conv3d_f32(const float* in, const float* wpacked, const float*
   DV_REQUIRE(k == 1 || k == 3, DV_ERR_UNSUPPORTED);
   DV_REQUIRE(stride == 1 || stride == 2, DV_ERR_UNSUPPORTED);
   DV_REQUIRE(!(k == 1 && stride != 1), DV_ERR_UNSUPPORTED);
+  DV_REQUIRE(!(Cout == 1 && k == 3 && stride != 1), DV_ERR_UNSUPPORTED);   // the single-channel head is packed for its own stride-1 kernel
   DV_REQUIRE(act >= DV_ACT_NONE && act <= DV_ACT_LEAKY, DV_ERR_UNSUPPORTED);
   DV_REQUIRE(dv_aligned16(wpacked), DV_ERR_ALIGN);
   ConvArgs a;

@@ -636,3 +636,11 @@ def test_patch_volume_vs_pytorch_depthwise(shape):
     dil = torch.tensor([1] * 8 + [2] * 16 + [3] * 16, dtype=torch.int32)
     out = patch_volume(dev(x), dev(w1), dev(w2), dev(dil))
     torch.testing.assert_close(out.cpu(), ref, atol=2e-5, rtol=1e-5)
+
+
+def test_single_channel_head_is_stride1_only():
+    """The Cout == 1 layer has its own packing / kernel (stride 1); other strides are refused, not mis-read."""
+    from diffuvolume_amd._lib import DiffuVolumeError
+    plan = S.Conv3dPlan(torch.randn(1, 8, 3, 3, 3, device=DEV), None, stride=2, act=S.ACT_NONE, precision="f32")
+    with pytest.raises(DiffuVolumeError):
+        plan(torch.randn(1, 8, 4, 4, 8, device=DEV))

@@ -132,3 +132,45 @@ for i in range(n):
     if rel(outp, refp) > 2e-5:
         bad2 += 1; print("patch FAIL", (b, d2, h2, w2), rel(outp, refp))
 print("second pass cases", n, "failures", bad2)
+
+# ---- third pass: conv3d prologue / residual / split-fp16, refinement inputs, gated conv2d ----
+from diffuvolume_amd.pwcnet_ddim import groupwise_corr_pm, warp
+bad3 = 0
+for i in range(n):
+    cin, cout = random.choice([8, 32, 64]), random.choice([16, 32, 64])
+    b, d, h, w = random.choice([1, 2]), random.randint(1, 6), random.randint(1, 9), random.randint(1, 60)
+    print('C3b', i, cin, cout, b, d, h, w, flush=True)
+    x = torch.randn(b, cin, d, h, w, device=dev)
+    sc = torch.rand(b, d, h, w, device=dev)
+    wt = torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.1
+    res = torch.randn(b, cout, d, h, w, device=dev)
+    bnp = bn(cout)
+    ref = torch.relu(F.batch_norm(F.conv3d(x * sc.unsqueeze(1), wt, None, 1, 1), bnp[2], bnp[3], bnp[0], bnp[1], False, 0.0, 1e-5) + res)
+    for prec in ("f32", "f16x3"):
+        out = S.Conv3dPlan(wt, bnp, stride=1, act=S.ACT_RELU, precision=prec)(x, in_scale=sc, residual=res); torch.cuda.synchronize()
+        if rel(out, ref) > 2e-5:
+            bad3 += 1; print("conv3d", prec, "FAIL", (cin, cout, b, d, h, w), rel(out, ref))
+    c, h2, w2 = random.choice([8, 20, 32]), random.randint(1, 12), random.randint(24, 200)
+    print('RI', i, c, h2, w2, flush=True)
+    fl, fr = torch.randn(b, c, h2, w2, device=dev), torch.randn(b, c, h2, w2, device=dev)
+    p3 = torch.rand(b, 1, h2, w2, device=dev) * 70 - 8
+    da, db = torch.randn(c, device=dev) * 0.1, torch.randn(c, device=dev) * 0.1
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        frw = warp(fr, p3)
+    aff = da.view(1, c, 1, 1) * p3 + db.view(1, c, 1, 1)
+    refr = torch.cat((fl - frw, fl, aff * torch.tanh(F.softplus(aff)), p3, groupwise_corr_pm(fl, frw, 24)), dim=1)
+    outr = S.refine_inputs(fl, fr, p3, da, db, 24); torch.cuda.synchronize()
+    if float((outr - refr).abs().max()) > 3e-4:      # the sample coordinate itself carries ~W * 2^-24 px of rounding
+        bad3 += 1; print("refine_inputs FAIL", (b, c, h2, w2), float((outr - refr).abs().max()))
+    parts = [torch.randn(b, cc, h2, w2, device=dev) for cc in random.sample([4, 6, 16, 30, 64], random.randint(1, 4))]
+    co = random.choice([16, 32, 40])
+    wt2 = torch.randn(co, sum(t.shape[1] for t in parts), 3, 3, device=dev) * 0.05
+    bias = torch.randn(co, device=dev) * 0.1
+    hh, zz = torch.randn(b, co, h2, w2, device=dev), torch.rand(b, co, h2, w2, device=dev)
+    v = torch.tanh(F.conv2d(torch.cat(parts, 1), wt2, bias, 1, 1))
+    outg = S.Conv2dPlan(wt2, None, act=S.ACT_TANH, bias=bias)(parts, blend=(zz, hh)); torch.cuda.synchronize()
+    if float((outg - ((1 - zz) * hh + zz * v)).abs().max()) > 2e-5:
+        bad3 += 1; print("gated cat conv2d FAIL", [t.shape[1] for t in parts], co, h2, w2)
+print("third pass cases", n, "failures", bad3)

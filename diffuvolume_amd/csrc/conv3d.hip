@@ -14,7 +14,6 @@
 // (ds_read_b32, lanes contiguous along x), B = w_s[tap][cin][cout].  Several blocks are
 // resident per CU so one block's staging overlaps another's MFMA stream.
 // MFMA-bound: 27*Cin*2 flop per output float (AI 86-864 flop/byte at fp32).
-#include <cstdlib>
 
 #include <type_traits>
 
@@ -551,19 +550,15 @@ extern "C" int dv_conv3d_f32(const float* in, const float* wpacked, const float*
   if (k == 3 && (a.Coutp >= 64 || stride == 2)) a.order = 1;
   if (k == 1 && a.Coutp >= 64) a.order = 2;
   hipStream_t s = (hipStream_t)stream;
-  // One 256-thread block per CU with the whole 512-entry register file per wave (WPS=1): big output
-  // bricks, next chunk prefetched in registers.  KS S NT MTX TH TD KC WPS
+  //                              KS S NT MTX TH TD KC WPS   (two blocks per CU everywhere)
   if (k == 3 && stride == 1) {
     if (Cout == 1) return launch_c1(a, s);
     if (a.Coutp == 16) return launch_conv<Geo<3, 1, 1, 2, 4, 4, 4, 2>>(a, s);
     if (a.Coutp == 32) {
-      static const int variant = getenv("DV_CONV_VARIANT") ? atoi(getenv("DV_CONV_VARIANT")) : 0;
-      // (32-wide tiles at three blocks per CU -- Geo<3,1,2,2,4,4,4,3>, 154 registers -- measured 120 vs 126 TFLOP/s)
-      if (a.Wo % 48 == 0 && variant == 0) return launch_conv<Geo<3, 1, 2, 3, 4, 4, 4, 2>>(a, s);
+      // 48-wide tiles when they divide the row (126 TFLOP/s; 32-wide tiles 120, also at three blocks per CU)
+      if (a.Wo % 48 == 0) return launch_conv<Geo<3, 1, 2, 3, 4, 4, 4, 2>>(a, s);
       return launch_conv<Geo<3, 1, 2, 2, 4, 4, 4, 2>>(a, s);
     }
-    static const int v64 = getenv("DV_CONV64_VARIANT") ? atoi(getenv("DV_CONV64_VARIANT")) : 0;
-    if (v64 == 1) return launch_conv<Geo<3, 1, 4, 2, 4, 4, 4, 2>>(a, s);
     return launch_conv<Geo<3, 1, 4, 2, 4, 2, 4, 2>>(a, s);
   }
   if (k == 3 && stride == 2) {

@@ -27,9 +27,14 @@ __device__ __forceinline__ float dv_act(float v, int act) {
   switch (act) {
     case DV_ACT_RELU: return fmaxf(v, 0.0f);
     case DV_ACT_MISH: {
-      // x * tanh(softplus(x)); softplus threshold 20 as torch (KITTI12/models/submodule.py:11-18)
-      float sp = v > 20.0f ? v : log1pf(expf(v));
-      return v * tanhf(sp);
+      // x * tanh(softplus(x)) (KITTI12/models/submodule.py:11-18).  With e = exp(x):
+      // tanh(log(1+e)) = ((1+e)^2 - 1) / ((1+e)^2 + 1) = n / (n + 2),  n = e * (e + 2)
+      // -- one exp and one division instead of exp + log1p + tanh (the Mish layers' epilogues were bound by
+      // those three).  No cancellation anywhere; x > 20 is torch's softplus threshold, where the factor is 1.
+      if (v > 20.0f) return v;
+      const float e = expf(v);
+      const float n = e * (e + 2.0f);
+      return v * (n / (n + 2.0f));
     }
     case DV_ACT_LEAKY: return v > 0.0f ? v : 0.01f * v;
     case DV_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));

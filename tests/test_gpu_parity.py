@@ -644,3 +644,31 @@ def test_single_channel_head_is_stride1_only():
     plan = S.Conv3dPlan(torch.randn(1, 8, 3, 3, 3, device=DEV), None, stride=2, act=S.ACT_NONE, precision="f32")
     with pytest.raises(DiffuVolumeError):
         plan(torch.randn(1, 8, 4, 4, 8, device=DEV))
+
+
+@pytest.mark.parametrize("steps", [2, 20])
+def test_ddim_sample_other_step_counts(acv_state_dict, steps):
+    """sampling_timesteps is a constructor argument here (hard-coded 5 / 3 / 2 in the reference; BASELINE config 5
+    asks for 20): time pairs, sigma/c coefficients and the ensemble weights follow the same rules for any S."""
+    import diffuvolume_amd as dv
+    cof = [0.5] + [0.0] * (steps - 1) + [0.5]
+    m = dv.ACVNet_DDIM(192, False, False, sampling_timesteps=steps, ensemble_cof=cof)
+    m.load_state_dict(acv_state_dict, strict=True)
+    m = m.to(DEV).eval()
+    vol = _volume(33, b=1, h=8, w=16)
+    used = torch.rand(1, 32, 64, generator=_gen(33, "u")) * 150 + 10
+    sd64 = _f64_state_dict(acv_state_dict)
+    orc, orc64 = O.ACVDiffusionOracle(acv_state_dict, sampling_timesteps=steps, cof=cof), O.ACVDiffusionOracle(sd64, sampling_timesteps=steps, cof=cof)
+    dq = torch.nn.functional.interpolate(used.unsqueeze(1), size=(8, 16), mode="bilinear") / 4
+    x_T = orc.encode_x_T(dq)
+    f32, s32 = orc.ddim_sample(vol, used, x_T, NoiseTape(7))
+    f64, s64 = orc64.ddim_sample(vol.double(), used.double(), x_T, NoiseTape(7))
+    with torch.no_grad():
+        fh, sh = m.ddim_sample(dev(vol), dev(used), dev(x_T), noise=NoiseTape(7))
+    assert sh.shape[0] == steps + 1 == s64.shape[0]
+    e_h, e_o = (sh.cpu().double() - s64).abs(), (s32.double() - s64).abs()
+    for i in (1, 2):
+        assert float(e_h[i].mean()) < 3 * float(e_o[i].mean()) + 5e-5, (i, float(e_h[i].mean()), float(e_o[i].mean()))
+    for i in range(1, steps + 1):
+        assert float(e_h[i].median()) < 5e-4, (i, float(e_h[i].median()))
+    assert float((fh.cpu().double() - f64).abs().median()) < 5e-4

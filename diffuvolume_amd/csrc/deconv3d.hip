@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
   const int nsk = a.skip ? (a.Cskip + 7) / 8 : 0;
   const int rr = lane >> 4, xq = (lane & 15) * 4;                      // this lane's skip row (pz,py) and column quad
   const size_t ovol2 = 8 * vol;
-  const bool lok = nsk > 0 && (z0 + zl) < a.D && (y0 + yl) < a.H && 2 * x0 + xq < 2 * a.W;   // 2W % 8 == 0: quad all in / out
+  const bool lok = nsk > 0 && (z0 + zl) < a.D && (y0 + yl) < a.H && 2 * x0 + xq < 2 * a.W;   // 2W % 4 == 0: quad all in / out
   const float* skl = nullptr;
   if (nsk > 0) {
 #pragma unroll
@@ -283,7 +283,9 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
   // Fast path (interior tiles, 16-byte aligned rows): everything address-like is either a scalar row base or
   // one of four precomputed 32-bit lane offsets, so an output row costs 4 packed FMAs, the activation and two
   // 16-byte stores -- the epilogue is issue-bound (it shares its SIMD with another block's MFMA stream).
-  const bool fast = a.fast_ok && co0 + kCOUT <= a.Cout && x0 + kTW <= a.W;
+  // (x tiles that hang over the row end take the same path: W is even, so each 16-byte half of a lane's eight
+  // outputs -- two input columns -- is all inside or all outside, and a lane predicate per half suffices)
+  const bool fast = a.fast_ok && co0 + kCOUT <= a.Cout;
   // ReLU / LeakyReLU / identity are max(v, slope * v) with slope 0 / 0.01 / 1; Mish has its own variant.
   const float slope = a.act == DV_ACT_RELU ? 0.f : (a.act == DV_ACT_LEAKY ? 0.01f : 1.f);
   auto epilogue_fast = [&](auto mishc, auto resc) __attribute__((always_inline)) {
@@ -291,6 +293,12 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
     constexpr bool RES = decltype(resc)::value;
     unsigned loff[kNT][kMTX];
     float sc[kNT], bi[kNT];
+    bool lo_ok[kMTX], hi_ok[kMTX];
+#pragma unroll
+    for (int m = 0; m < kMTX; ++m) {
+      lo_ok[m] = x0 + m * 16 + 4 * kq + 1 < a.W;
+      hi_ok[m] = x0 + m * 16 + 4 * kq + 3 < a.W;
+    }
 #pragma unroll
     for (int n = 0; n < kNT; ++n) {
       const int co = co0 + n * 16 + j;
@@ -311,8 +319,8 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
       const char* rrow = reinterpret_cast<const char*>(a.residual + rowo(q >> 1));
 #pragma unroll
       for (int m = 0; m < kMTX; ++m) {
-        rv[q % RD][m][0] = *reinterpret_cast<const f32x4*>(rrow + loff[q & 1][m]);
-        rv[q % RD][m][1] = *reinterpret_cast<const f32x4*>(rrow + loff[q & 1][m] + 16);
+        rv[q % RD][m][0] = lo_ok[m] ? *reinterpret_cast<const f32x4*>(rrow + loff[q & 1][m]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        rv[q % RD][m][1] = hi_ok[m] ? *reinterpret_cast<const f32x4*>(rrow + loff[q & 1][m] + 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
       }
     };
     if (RES) {
@@ -341,8 +349,8 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
           lo[r] = MISH ? dv_act(lo[r], DV_ACT_MISH) : fmaxf(lo[r], lo[r] * slope);
           hi[r] = MISH ? dv_act(hi[r], DV_ACT_MISH) : fmaxf(hi[r], hi[r] * slope);
         }
-        *reinterpret_cast<f32x4*>(orow + loff[n][m]) = lo;
-        *reinterpret_cast<f32x4*>(orow + loff[n][m] + 16) = hi;
+        if (lo_ok[m]) *reinterpret_cast<f32x4*>(orow + loff[n][m]) = lo;
+        if (hi_ok[m]) *reinterpret_cast<f32x4*>(orow + loff[n][m] + 16) = hi;
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -466,10 +474,11 @@ int run_any(const float* in, const float* wpacked, const float* ch_scale, const 
   a.ntz = (D + kTD - 1) / kTD;
   a.nco = a.Coutp / kCOUT;
   a.act = act;
-  a.vec_store = (W % 4 == 0) && dv_aligned16(out) && (!residual || dv_aligned16(residual));
+  a.vec_store = (W % 4 == 0) && dv_aligned16(out) && (!residual || dv_aligned16(residual));   // generic path's 32-byte stores
   if ((size_t)D * H * W * sizeof(float) > 0xffffffffull) return DV_ERR_SHAPE;   // 32-bit in-channel byte offsets
   // fast epilogue: scalar row base + 32-bit per-lane byte offsets inside one batch item
-  a.fast_ok = a.vec_store && (size_t)Cout * 8 * D * H * W * sizeof(float) <= 0xffffffffull;
+  a.fast_ok = (W % 2 == 0) && dv_aligned16(out) && (!residual || dv_aligned16(residual)) &&
+              (size_t)Cout * 8 * D * H * W * sizeof(float) <= 0xffffffffull;
   return K == 3 ? launch_deconv<3, 8>(a, s) : launch_deconv<4, 4>(a, s);
 }
 
@@ -531,7 +540,7 @@ extern "C" int dv_deconv3d_k3s2_redir_f32(const float* in, const float* wpacked,
   DV_REQUIRE_PTR(skip);
   DV_REQUIRE_PTR(redir_w);
   DV_REQUIRE(Cskip > 0, DV_ERR_SHAPE);
-  DV_REQUIRE(W % 4 == 0 && dv_aligned16(skip), DV_ERR_UNSUPPORTED);     // 16-byte skip quads never straddle a row end
+  DV_REQUIRE(W % 2 == 0 && dv_aligned16(skip), DV_ERR_UNSUPPORTED);     // 16-byte skip quads never straddle a row end
   DV_REQUIRE((Cskip + 7) / 8 <= (Cin + 7) / 8, DV_ERR_UNSUPPORTED);       // skip chunks ride on the main chunks
   return run_any(in, wpacked, nullptr, ch_bias, nullptr, out, B, Cin, D, H, W, Cout, act, 3, (hipStream_t)stream, skip,
                  redir_w, Cskip);

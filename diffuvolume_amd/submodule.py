@@ -441,7 +441,7 @@ class Deconv3dPlan:
             skip = _dev_f32(skip, "skip")
             if tuple(skip.shape) != (b, self.cskip, 2 * d, 2 * h, 2 * w):
                 raise RuntimeError("skip shape mismatch")
-            if w % 4 == 0 and (self.cskip + 7) // 8 <= (cin + 7) // 8:
+            if w % 2 == 0 and (self.cskip + 7) // 8 <= (cin + 7) // 8:
                 lib = _lib.load()
                 with torch.cuda.device(x.device):
                     nb = 4.0 * (x.numel() + out.numel() + skip.numel())

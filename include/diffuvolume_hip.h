@@ -177,7 +177,7 @@ int dv_feature_gate_f32(const float* cv /*[B,C,D,H,W]*/, const float* logit /*[B
  *   out = act( deconv3d_k3s2(in, w) + redir_w . skip + ch_bias )
  * Both BatchNorm scales must already be folded into `w` (before dv_deconv3d_pack_weights_f32) and `redir_w`
  * ([Cout][Cskip] row-major, device), their shifts summed into ch_bias.  skip [B,Cskip,2D,2H,2W].
- * Needs W % 4 == 0 and ceil(Cskip/8) <= ceil(Cin/8); otherwise DV_ERR_UNSUPPORTED (run the two layers apart). */
+ * Needs W % 2 == 0 and ceil(Cskip/8) <= ceil(Cin/8); otherwise DV_ERR_UNSUPPORTED (run the two layers apart). */
 int dv_deconv3d_k3s2_redir_f32(const float* in, const float* wpacked, const float* ch_bias, const float* skip,
                                const float* redir_w, float* out, int B, int Cin, int D, int H, int W, int Cout,
                                int Cskip, int act, dv_stream_t stream);

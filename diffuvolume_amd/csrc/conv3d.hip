@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256, G::WPS) void conv3d_mfma_kernel(ConvArgs a) {
   constexpr int ROWQ = G::COUT * 2 / 4;                   // float4 per (cinpair, tap) weight row
   constexpr int NQ = (G::KC / 2) * G::T * ROWQ;           // float4 per weight chunk
   constexpr int NWQ = (NQ + 255) / 256;
-  int sp[NS];       // offset inside one channel volume, -1 = zero padding
+  unsigned sob[NS];                 // byte offset inside one channel volume (0 where the brick leaves the volume)
+  unsigned okmask = 0;              // bit i: position i is inside the volume
   float scl[HAS_SCALE ? NS : 1];    // the `volume * noise` prologue factor of that position
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
@@ -134,20 +135,23 @@ __global__ __launch_bounds__(256, G::WPS) void conv3d_mfma_kernel(ConvArgs a) {
     const int z = zi0 + zz, y = yi0 + yy, x = xi0 + xx;
     const bool ok = r < G::PRAW && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H &&
                     (unsigned)x < (unsigned)a.W;
-    sp[i] = ok ? (z * a.H + y) * a.W + x : -1;
-    if (HAS_SCALE) scl[i] = (ok && scb) ? scb[sp[i]] : 1.f;
+    const unsigned sp = ok ? (unsigned)((z * a.H + y) * a.W + x) : 0u;
+    sob[i] = sp * 4u;
+    okmask |= ok ? (1u << i) : 0u;
+    if (HAS_SCALE) scl[i] = (ok && scb) ? scb[sp] : 1.f;
   }
   float vin[G::KC][NS];
   f32x4 vw[NWQ];
   // global -> registers for one chunk of KC input channels (issued one chunk ahead of its use,
-  // so HBM/L2 latency hides behind the previous chunk's MFMA stream)
+  // so HBM/L2 latency hides behind the previous chunk's MFMA stream).  Loads are unconditional (scalar channel
+  // base + 32-bit lane offset); the zero padding is applied when the values are committed to LDS.
   auto fetch = [&](int c0) {
 #pragma unroll
     for (int cl = 0; cl < G::KC; ++cl) {
-      const float* src = inb + (size_t)(c0 + cl) * vol;
-      const bool cok = (c0 + cl) < a.Cin;
+      const int ch = (c0 + cl) < a.Cin ? c0 + cl : 0;
+      const char* src = reinterpret_cast<const char*>(inb + (size_t)ch * vol);
 #pragma unroll
-      for (int i = 0; i < NS; ++i) vin[cl][i] = (cok && sp[i] >= 0) ? src[sp[i]] : 0.f;
+      for (int i = 0; i < NS; ++i) vin[cl][i] = *reinterpret_cast<const float*>(src + sob[i]);
     }
     const float* wsrc = a.wpk + ((size_t)(c0 >> 1) * G::T * a.Coutp + co0) * 2;
 #pragma unroll
@@ -157,14 +161,17 @@ __global__ __launch_bounds__(256, G::WPS) void conv3d_mfma_kernel(ConvArgs a) {
       if (e < NQ) vw[q] = reinterpret_cast<const f32x4*>(wsrc + (size_t)row * a.Coutp * 2)[qq];
     }
   };
-  auto commit = [&]() {  // registers -> LDS
+  auto commit = [&](int c0) {  // registers -> LDS
 #pragma unroll
-    for (int cl = 0; cl < G::KC; ++cl)
+    for (int cl = 0; cl < G::KC; ++cl) {
+      const bool cok = (c0 + cl) < a.Cin;
 #pragma unroll
       for (int i = 0; i < NS; ++i) {
         const int r = tid + 256 * i;
-        if (r < G::PRAW) in_s[cl * G::P + r] = HAS_SCALE ? vin[cl][i] * scl[i] : vin[cl][i];
+        const float v = (cok && ((okmask >> i) & 1u)) ? vin[cl][i] : 0.f;
+        if (r < G::PRAW) in_s[cl * G::P + r] = HAS_SCALE ? v * scl[i] : v;
       }
+    }
 #pragma unroll
     for (int q = 0; q < NWQ; ++q) {
       const int e = tid + 256 * q;
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(256, G::WPS) void conv3d_mfma_kernel(ConvArgs a) {
   fetch(0);
   for (int c0 = 0; c0 < a.Cin; c0 += G::KC) {
     __syncthreads();  // previous chunk's MFMAs are done reading LDS
-    commit();
+    commit(c0);
     __syncthreads();
     if (c0 + G::KC < a.Cin) fetch(c0 + G::KC);
     // ---- MFMA stream: one k-step (4 input channels) per tap.  (dz,dy) are real loops so the
@@ -528,6 +535,7 @@ extern "C" int dv_conv3d_f32(const float* in, const float* wpacked, const float*
   DV_REQUIRE(k == 1 || k == 3, DV_ERR_UNSUPPORTED);
   DV_REQUIRE(stride == 1 || stride == 2, DV_ERR_UNSUPPORTED);
   DV_REQUIRE(!(k == 1 && stride != 1), DV_ERR_UNSUPPORTED);
+  DV_REQUIRE((size_t)D * H * W * sizeof(float) <= 0xffffffffull, DV_ERR_SHAPE);    // 32-bit byte offsets inside a channel
   DV_REQUIRE(!(Cout == 1 && k == 3 && stride != 1), DV_ERR_UNSUPPORTED);   // the single-channel head is packed for its own stride-1 kernel
   DV_REQUIRE(act >= DV_ACT_NONE && act <= DV_ACT_LEAKY, DV_ERR_UNSUPPORTED);
   DV_REQUIRE(dv_aligned16(wpacked), DV_ERR_ALIGN);

@@ -106,8 +106,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16x3_kernel(Args a) {
   // staging plan: thread owns NS brick positions (all 8 channels of each)
   constexpr int NS = (NREAL + 255) / 256;
   constexpr int NWQ = (2 * W_H8 + 255) / 256;
-  int sp[NS];
-  float scl[HAS_SCALE ? NS : 1];
+  unsigned sob[NS];                 // byte offset inside one channel volume (0 outside the volume)
+  unsigned okmask = 0;              // bit i: position i is inside the volume
+  float scl[HAS_SCALE ? NS : 1];    // activation scale x `volume * noise` factor
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
     const int r = tid + 256 * i;
@@ -116,18 +117,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16x3_kernel(Args a) {
     const int z = z0 - 1 + zz, y = y0 - 1 + yy, x = x0 - 1 + xx;
     const bool ok = r < NREAL && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H &&
                     (unsigned)x < (unsigned)a.W;
-    sp[i] = ok ? (z * a.H + y) * a.W + x : -1;
-    if (HAS_SCALE) scl[i] = (ok && scb) ? scb[sp[i]] * kActScale : kActScale;
+    const unsigned sp = ok ? (unsigned)((z * a.H + y) * a.W + x) : 0u;
+    sob[i] = sp * 4u;
+    okmask |= ok ? (1u << i) : 0u;
+    if (HAS_SCALE) scl[i] = (ok && scb) ? scb[sp] * kActScale : kActScale;
   }
   float vin[NS][KC];
   f32x4 vw[NWQ];
   auto fetch = [&](int c0) {
 #pragma unroll
     for (int cl = 0; cl < KC; ++cl) {
-      const float* src = inb + (size_t)(c0 + cl) * vol;
-      const bool cok = (c0 + cl) < a.Cin;
+      const char* src = reinterpret_cast<const char*>(inb + (size_t)((c0 + cl) < a.Cin ? c0 + cl : 0) * vol);
 #pragma unroll
-      for (int i = 0; i < NS; ++i) vin[i][cl] = (cok && sp[i] >= 0) ? src[sp[i]] : 0.f;
+      for (int i = 0; i < NS; ++i) vin[i][cl] = *reinterpret_cast<const float*>(src + sob[i]);   // unconditional
     }
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpk) + (size_t)(c0 / KC) * 2 * KB * 4 * a.Coutp;
 #pragma unroll
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16x3_kernel(Args a) {
     }
   };
   float vmax = 0.f;   // largest scaled magnitude this thread has split (range guard)
-  auto commit = [&]() {
+  auto commit = [&](int c0) {
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
       const int r = tid + 256 * i;
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16x3_kernel(Args a) {
         // pair would be one fp16 ulp apart (seen once per ~10^4 elements before this was pinned)
         // (hipcc fused it even through __fmul_rn/__fsub_rn: v_fma_mixlo_f16 for lo, v_cvt_pk_f16_f32 of
         // the rounded product for hi -- the empty asm makes v opaque so the two cannot be re-derived.)
-        float v = vin[i][cl] * (HAS_SCALE ? scl[i] : kActScale);
+        float v = ((c0 + cl) < a.Cin && ((okmask >> i) & 1u)) ? vin[i][cl] * (HAS_SCALE ? scl[i] : kActScale) : 0.f;
         asm volatile("" : "+v"(v));
         vmax = fmaxf(vmax, fabsf(v));
         const _Float16 h = (_Float16)v;
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16x3_kernel(Args a) {
   fetch(0);
   for (int c0 = 0; c0 < a.Cin; c0 += KC) {
     __syncthreads();
-    commit();
+    commit(c0);
     __syncthreads();
     if (c0 + KC < a.Cin) fetch(c0 + KC);
     // MFMA stream.  (A hand-pipelined variant -- A fragments two M-tiles ahead through a register ring,

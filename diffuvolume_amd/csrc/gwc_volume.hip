@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void gwc_rows_kernel(const float* __restrict__
   const int rowq = padq + nq;                  // quads per staged channel row
   float4* rows = reinterpret_cast<float4*>(smem) + (size_t)wave * CPG * rowq;
 
-  const int row = blockIdx.x * kRowsPerBlock + wave;   // (b*G + g)*H + y
+  const int row = blockIdx.x * (blockDim.x >> 6) + wave;   // (b*G + g)*H + y; one wave per row
   const bool live = row < total_rows;
   const int y = live ? row % H : 0;
   const int bg = live ? row / H : 0;
@@ -130,10 +130,12 @@ int launch_rows(const float* ref, const float* tgt, float* out, int B, int C, in
                 int G, hipStream_t s) {
   const int total_rows = B * G * H;
   const int rowq = ((D + 3) / 4 + 1) + W / 4;
-  const size_t lds = (size_t)kRowsPerBlock * CPG * rowq * sizeof(float4);
+  int rpb = kRowsPerBlock;                       // rows (= waves) per block: as many as fit 64 KB of LDS
+  while (rpb > 1 && (size_t)rpb * CPG * rowq * sizeof(float4) > 64 * 1024) rpb >>= 1;
+  const size_t lds = (size_t)rpb * CPG * rowq * sizeof(float4);
   if (lds > 64 * 1024) return DV_ERR_UNSUPPORTED;
-  const int blocks = (total_rows + kRowsPerBlock - 1) / kRowsPerBlock;
-  hipLaunchKernelGGL(gwc_rows_kernel<CPG>, dim3(blocks), dim3(256), lds, s, ref, tgt, out, C, H, W,
+  const int blocks = (total_rows + rpb - 1) / rpb;
+  hipLaunchKernelGGL(gwc_rows_kernel<CPG>, dim3(blocks), dim3(64 * rpb), lds, s, ref, tgt, out, C, H, W,
                      D, G, total_rows);
   return dv_launch_status();
 }

@@ -437,6 +437,10 @@ static int conv2d_run(const float* in, const float* const* more, const int* more
       const long long rows = (long long)B * ((H + 7) / 8) * ((Cout + 31) / 32);
       const long long b64 = rows * ((W + 63) / 64), b32 = rows * ((W + 31) / 32);
       auto eff = [](long long blocks) { return (double)blocks / (double)((blocks + 767) / 768 * 768); };
+      // very small problems (a single IGEV pair: 480 blocks of 8 x 32 pixels) would leave most of the chip idle
+      // behind long serial K loops: 4 x 32-pixel tiles double the block count (16 accumulator registers, many
+      // resident waves per SIMD).  (Staging 16 channels per barrier round on top of that was slower.)
+      if (b32 < 1024) return launch2d<G2<3, 2, 4, 4, false, 1, 4, 2>>(a, s);
       if (eff(b32) > 1.15 * eff(b64)) return launch2d<G2<3, 2, 4, 4, false, 2, 3, 2>>(a, s);
       return launch2d<G2<3, 2, 4, 4, false, 2, 3>>(a, s);
     }

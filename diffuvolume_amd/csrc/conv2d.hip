@@ -444,6 +444,10 @@ static int conv2d_run(const float* in, const float* const* more, const int* more
       if (eff(b32) > 1.15 * eff(b64)) return launch2d<G2<3, 2, 4, 4, false, 2, 3, 2>>(a, s);
       return launch2d<G2<3, 2, 4, 4, false, 2, 3>>(a, s);
     }
+    {   // <= 16 output channels (heads with one channel): the same rule on the block count
+      const long long rows1 = (long long)B * ((H + 7) / 8) * ((Cout + 15) / 16);
+      if (rows1 * ((W + 31) / 32) < 1024) return launch2d<G2<3, 1, 4, 4, false, 1, 4, 2>>(a, s);
+    }
     return launch2d<G2<3, 1, 4, 4, false, 2, 3>>(a, s);
   }
   if (NT == 2) return launch2d<G2<3, 2, 4, 16, true, 2, 2>>(a, s);   // 9 staged positions per thread: spills at 170 registers

@@ -211,14 +211,23 @@ class Conv3dPlan:
             raise _lib.DiffuVolumeError(f"unsupported Conv3d kernel {tuple(w.shape[2:])}")
         self.k, self.stride, self.act = k, stride, act
         precision = precision or default_conv_precision()
-        if precision not in ("f32", "f16x3"):
-            raise ValueError("precision must be 'f32' (v_mfma_f32_16x16x4_f32) or 'f16x3' (split-fp16 MFMA)")
+        if precision not in ("f32", "f32_direct", "f16x3"):
+            raise ValueError("precision must be 'f32' (v_mfma_f32_16x16x4_f32; Winograd F(2x2,3x3) in-plane for the "
+                             "3x3x3 stride-1 layers), 'f32_direct' (the same instruction, direct taps everywhere) "
+                             "or 'f16x3' (split-fp16 MFMA)")
         # the split-fp16 kernel covers the 3x3x3 stride-1 layers (32 output channels per block; wider
         # layers are split over the grid); the single-channel head stays on its vector-ALU kernel
         self.split = precision == "f16x3" and k == 3 and stride == 1 and self.cout > 1
+        self.wino = precision == "f32" and k == 3 and stride == 1 and self.cout > 1
         lib = _lib.load()
         with torch.cuda.device(w.device):
-            if self.split:
+            if self.wino:
+                n = lib.dv_conv3d_wino_packed_floats(self.cin, self.cout)
+                self.wpacked = torch.empty(n, dtype=torch.float32, device=w.device)
+                _lib.check(lib.dv_conv3d_wino_pack_weights_f32(w.data_ptr(), self.wpacked.data_ptr(), self.cin,
+                                                               self.cout, _lib.stream_ptr()),
+                           "dv_conv3d_wino_pack_weights_f32")
+            elif self.split:
                 nbytes = lib.dv_conv3d_f16x3_packed_bytes(self.cin, self.cout)
                 self.wpacked = torch.empty(nbytes // 2, dtype=torch.float16, device=w.device)
                 _lib.check(lib.dv_conv3d_f16x3_pack_weights(w.data_ptr(), self.wpacked.data_ptr(), self.cin,
@@ -270,6 +279,16 @@ class Conv3dPlan:
                                                                  b, cin, d, h, w, self.cout,
                                                                  self.act, _lib.stream_ptr()),
                                          "dv_conv3d_f16x3_f32"))
+                return out
+            if self.wino:
+                timed(f"conv3d_k3s1_co{self.cout}" + ("" if in_scale is None else "_filter"),
+                      2.0 * out.numel() * cin * 27, nb,
+                      lambda: _lib.check(lib.dv_conv3d_wino_f32(x.data_ptr(), self.wpacked.data_ptr(),
+                                                                _lib.ptr(self.scale), _lib.ptr(self.shift),
+                                                                _lib.ptr(in_scale), _lib.ptr(residual),
+                                                                out.data_ptr(), b, cin, d, h, w, self.cout,
+                                                                self.act, _lib.stream_ptr()),
+                                         "dv_conv3d_wino_f32"))
                 return out
             timed(f"conv3d_k{self.k}s{self.stride}_co{self.cout}" + ("" if in_scale is None else "_filter"),
                   2.0 * out.numel() * cin * self.k ** 3, nb,

@@ -98,6 +98,18 @@ int dv_conv3d_f16x3_f32(const float* in, const void* wpacked, const float* ch_sc
                         const float* in_scale, const float* residual, float* out, int* overflow_flag,
                         int B, int Cin, int D, int H, int W, int Cout, int act, dv_stream_t stream);
 
+/* The same 3x3x3 stride-1 layer with the two in-plane taps computed by the Winograd minimal-filtering transform
+ * F(2x2,3x3) (depth taps direct): 2.25x fewer multiplies, still on v_mfma_f32_16x16x4_f32 with fp32 operands and
+ * accumulation (csrc/conv3d_wino.hip).  The transforms only add / subtract (the 1/2 factors are folded into the
+ * packed weights), so results differ from dv_conv3d_f32 by fp32 rounding of a few extra additions per product.
+ * Same arguments and epilogue as dv_conv3d_f32 (k = 3, stride = 1); `wpacked` from dv_conv3d_wino_pack_weights_f32. */
+size_t dv_conv3d_wino_packed_floats(int Cin, int Cout);
+int dv_conv3d_wino_pack_weights_f32(const float* w /*[Cout,Cin,3,3,3]*/, float* wpacked, int Cin, int Cout,
+                                    dv_stream_t stream);
+int dv_conv3d_wino_f32(const float* in, const float* wpacked, const float* ch_scale, const float* ch_bias,
+                       const float* in_scale, const float* residual, float* out,
+                       int B, int Cin, int D, int H, int W, int Cout, int act, dv_stream_t stream);
+
 /* nn.ConvTranspose3d(k=3, stride=2, padding=1, output_padding=1, bias=False) + BN
  * + skip add + activation: acv_ddim.py:74-80 and :91-92.  w [Cin,Cout,3,3,3].
  * in [B,Cin,D,H,W] -> out [B,Cout,2D,2H,2W]. */

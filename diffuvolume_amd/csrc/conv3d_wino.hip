@@ -29,17 +29,15 @@ namespace wg {
 constexpr int KC = 4, NT = 2, TD = 4, TH = 4, TW = 16;
 constexpr int IZ = TD + 2, IY = TH + 2, IX = TW + 2;
 constexpr int PRAW = IZ * IY * IX;          // 648 raw positions per channel
-constexpr int RAWP = 656;                   // channel stride of the raw brick: = 16 mod 64, so 8 tiles x 4 channels
-                                            // of ds_read_b64 cover the 64 banks once
-constexpr int TS = 20;                      // tile (and cout) row stride: 16 positions + 4, j*20 mod 64 distinct slots
-constexpr int VPL = 16 * TS;                // one plane of V / one k-row block of U
-constexpr int VC = IZ * VPL;                // channel stride of V (= 0 mod 64)
-constexpr int V_FLOATS = KC * VC;
-constexpr int U_FLOATS = 3 * NT * KC * VPL;
+// raw brick [c][z][y][RX]: row stride 24 and channel stride 864 (= 32 mod 64) put the 16 tiles x 2 channels a
+// 32-lane half reads with one ds_read_b64 (tile columns 2 floats apart, tile rows 2*RX = 48 apart) on 64 distinct banks
+constexpr int RX = 24;
+constexpr int RAWP = IZ * IY * RX;
 constexpr int RAW_FLOATS = KC * RAWP;
-constexpr int U_CHUNK = 3 * NT * KC * 16 * 16;   // packed floats per (chunk, co block)
+constexpr int U_CHUNK = 3 * NT * KC * 16 * 16;   // packed floats per (chunk, co block) = the LDS image, 24 KB
 constexpr int NS = (PRAW + 255) / 256;
-static_assert((V_FLOATS + U_FLOATS + RAW_FLOATS) * 4 * 2 <= 160 * 1024, "two blocks per CU");
+static_assert(RAWP % 64 == 32, "bank plan of the patch reads");
+static_assert((RAW_FLOATS + U_CHUNK) * 2 * 4 * 2 <= 160 * 1024, "two blocks per CU, both stages double-buffered");
 }  // namespace wg
 
 struct WinoArgs {
@@ -59,10 +57,9 @@ struct WinoArgs {
 template <bool HAS_SCALE>
 __global__ __launch_bounds__(256, 2) void conv3d_wino_kernel(WinoArgs a) {
   using namespace wg;
-  __shared__ __attribute__((aligned(16))) float smem[V_FLOATS + U_FLOATS + RAW_FLOATS];
-  float* v_s = smem;
-  float* u_s = smem + V_FLOATS;
-  float* raw_s = u_s + U_FLOATS;
+  __shared__ __attribute__((aligned(1024))) float smem[2 * U_CHUNK + 2 * RAW_FLOATS];
+  float* u_s = smem;
+  float* raw_s = smem + 2 * U_CHUNK;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -89,7 +86,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_wino_kernel(WinoArgs a) {
   const float* scb = (HAS_SCALE && a.in_scale) ? a.in_scale + (size_t)b * vol : nullptr;
 
   // ---- raw staging plan: NS positions of the haloed brick per thread, the same for every channel ----
-  unsigned sob[NS];
+  unsigned sob[NS];                 // byte offset in a channel volume
+  int lro[NS];                      // float offset in a channel of the LDS brick
   unsigned okmask = 0;
   float scl[HAS_SCALE ? NS : 1];
 #pragma unroll
@@ -102,12 +100,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_wino_kernel(WinoArgs a) {
                     (unsigned)x < (unsigned)a.W;
     const unsigned sp = ok ? (unsigned)((z * a.H + y) * a.W + x) : 0u;
     sob[i] = sp * 4u;
+    lro[i] = r < PRAW ? (zz * IY + yy) * RX + xx : IX;      // lanes past the brick write a column no patch reads
     okmask |= ok ? (1u << i) : 0u;
     if (HAS_SCALE) scl[i] = (ok && scb) ? scb[sp] : 1.f;
   }
-  float vin[KC][NS];
-  f32x4 vu[6];
-  auto fetch_raw = [&](int c0) __attribute__((always_inline)) {
+  float vinA[KC][NS], vinB[KC][NS];   // raw loads run two chunks ahead of their use: two register sets
+  auto fetch_raw = [&](int c0, float (&vin)[KC][NS]) __attribute__((always_inline)) {
 #pragma unroll
     for (int cl = 0; cl < KC; ++cl) {
       const int ch = (c0 + cl) < a.Cin ? c0 + cl : 0;
@@ -116,150 +114,194 @@ __global__ __launch_bounds__(256, 2) void conv3d_wino_kernel(WinoArgs a) {
       for (int i = 0; i < NS; ++i) vin[cl][i] = *reinterpret_cast<const float*>(src + sob[i]);
     }
   };
-  auto commit_raw = [&](int c0) __attribute__((always_inline)) {
+  auto commit_raw = [&](int c0, float* rb, float (&vin)[KC][NS]) __attribute__((always_inline)) {
 #pragma unroll
     for (int cl = 0; cl < KC; ++cl) {
       const bool cok = (c0 + cl) < a.Cin;
 #pragma unroll
       for (int i = 0; i < NS; ++i) {
-        const int r = tid + 256 * i;
         const float v = (cok && ((okmask >> i) & 1u)) ? vin[cl][i] : 0.f;
-        if (r < PRAW) raw_s[cl * RAWP + r] = HAS_SCALE ? v * scl[i] : v;
+        rb[cl * RAWP + lro[i]] = HAS_SCALE ? v * scl[i] : v;
       }
     }
   };
-  auto fetch_u = [&](int c0) __attribute__((always_inline)) {
-    const f32x4* src = reinterpret_cast<const f32x4*>(a.wpk + ((size_t)(c0 >> 2) * a.nco + tc) * U_CHUNK);
-#pragma unroll
-    for (int q = 0; q < 6; ++q) vu[q] = src[tid + 256 * q];
-  };
-  auto commit_u = [&]() __attribute__((always_inline)) {
+  // ---- weights: the packed chunk is the LDS image; LDS-DMA copies it in 1-KB pieces (16 cout rows x 4 position
+  // quads), six per wave.  Lane l of a piece lands in 16-byte slot l, so the source quad is XOR-swizzled with the
+  // row (slot s of row n holds quad s ^ (n>>2)): the B-fragment ds_read_b128 of 16 rows then covers 16 distinct
+  // slots of the 256-byte bank row without padding ----
+  const int dma_lo = (lane >> 2) * 16 + (((lane & 3) ^ ((lane >> 4) & 3)) * 4);
+  auto dma_u = [&](int c0, float* ub) __attribute__((always_inline)) {
+    const float* src = a.wpk + ((size_t)(c0 >> 2) * a.nco + tc) * U_CHUNK + dma_lo;
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
-      const int e = tid + 256 * q;
-      reinterpret_cast<f32x4*>(u_s)[(e >> 2) * 5 + (e & 3)] = vu[q];
-    }
-  };
-  // ---- input transform: 768 units = 4 channels x 6 planes x 16 tiles x 2 halves (two of the four transform
-  // rows each); a 32-lane half reads 8 tile columns x 4 channels = one bank row per ds_read_b64 ----
-  auto transform = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int u = tid + 256 * i;
-      const int ttx = u & 7, cl = (u >> 3) & 3, rest = u >> 5;       // rest 0..23
-      const int half = rest >= 12 ? 1 : 0, rr = rest - half * 12;
-      const int pl = rr >> 1, tty = rr & 1;
-      const float* rp = raw_s + cl * RAWP + (pl * IY + 2 * tty + half) * IX + 2 * ttx;
-      f32x2 e[3][2];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        e[k][0] = *reinterpret_cast<const f32x2*>(rp + k * IX);
-        e[k][1] = *reinterpret_cast<const f32x2*>(rp + k * IX + 2);
-      }
-      float r0[4], r1[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float e0 = e[0][c >> 1][c & 1], e1 = e[1][c >> 1][c & 1], e2 = e[2][c >> 1][c & 1];
-        // half 0: rows d0-d2, d1+d2 (e = d0,d1,d2);  half 1: rows d2-d1, d1-d3 (e = d1,d2,d3)
-        r0[c] = half ? e1 - e0 : e0 - e2;
-        r1[c] = half ? e0 - e2 : e1 + e2;
-      }
-      float* vp = v_s + cl * VC + pl * VPL + (tty * 8 + ttx) * TS + half * 8;
-      *reinterpret_cast<f32x4*>(vp) = (f32x4){r0[0] - r0[2], r0[1] + r0[2], r0[2] - r0[1], r0[1] - r0[3]};
-      *reinterpret_cast<f32x4*>(vp + 4) = (f32x4){r1[0] - r1[2], r1[1] + r1[2], r1[2] - r1[1], r1[1] - r1[3]};
+      const int piece = wave + 4 * q;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 256),
+                                       (__attribute__((address_space(3))) void*)(ub + piece * 256), 16, 0, 0);
     }
   };
 
-  fetch_raw(0);
-  fetch_u(0);
-  commit_raw(0);
-  if (KC < a.Cin) fetch_raw(KC);
-  const float* ap0 = v_s + kq * VC + wave * VPL + j * TS;
-  const float* bp0 = u_s + kq * VPL + j * TS;
-  for (int c0 = 0; c0 < a.Cin; c0 += KC) {
-    __syncthreads();     // the previous chunk's MFMAs are done with V and U; the raw brick of this chunk is complete
-    transform();
-    commit_u();
+  // this lane's 4x4 patch: tile (row j&1, column j>>1) of plane wave+kd, channel kq;  B rows (kq, j)
+  const int patch_lo = kq * RAWP + (wave * IY + 2 * (j & 1)) * RX + 2 * (j >> 1);
+  int b_lo[4];
+#pragma unroll
+  for (int p4 = 0; p4 < 4; ++p4) b_lo[p4] = (kq * 16 + j) * 16 + ((p4 ^ ((j >> 2) & 3)) * 4);
+
+  fetch_raw(0, vinA);
+  dma_u(0, u_s);
+  commit_raw(0, raw_s, vinA);
+  if (KC < a.Cin) fetch_raw(KC, vinA);
+  if (2 * KC < a.Cin) fetch_raw(2 * KC, vinB);
+  // one chunk: `vin` holds the raw brick of chunk c0+KC on entry and that of chunk c0+3*KC on exit
+  auto chunk = [&](int c0, int cur, float (&vin)[KC][NS]) __attribute__((always_inline)) {
+    // this chunk's weights (DMA, issued one chunk ago) have to be in LDS; the raw loads issued after them (12 per
+    // thread, for chunk c0+2*KC) may stay in flight.  After the barrier every wave is done with the other pair of
+    // buffers and this chunk's raw brick is complete.
+#ifndef ABL_NOSYNC
+    if (c0 + 2 * KC < a.Cin) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#endif
     if (c0 + KC < a.Cin) {
-      commit_raw(c0 + KC);
-      fetch_u(c0 + KC);
-      if (c0 + 2 * KC < a.Cin) fetch_raw(c0 + 2 * KC);
+#ifndef ABL_NOU
+      dma_u(c0 + KC, u_s + (cur ^ 1) * U_CHUNK);
+#endif
+#ifndef ABL_NORAW
+      commit_raw(c0 + KC, raw_s + (cur ^ 1) * RAW_FLOATS, vin);
+      if (c0 + 3 * KC < a.Cin) fetch_raw(c0 + 3 * KC, vin);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll 1
-    for (int kd = 0; kd < 3; ++kd) {
-      const float* ap = ap0 + kd * VPL;
-      const float* bp = bp0 + kd * (NT * KC * VPL);
+    const float* rb = raw_s + cur * RAW_FLOATS + patch_lo;
+    const float* ub = u_s + cur * U_CHUNK;
+    // MFMA stream: 12 groups (kd, position quad) of 8 MFMAs.  The B fragments of group g+1, the raw patch of the
+    // next plane and its transform are issued in the shadow of group g (sched_barrier pins that order).
+    f32x2 d[4][2];
+    f32x4 bq[2][NT];
+    f32x2 vp[2][4][2];      // V of the current / next plane: [row][column pair]
+    auto load_patch = [&](int kd) __attribute__((always_inline)) {
 #pragma unroll
-      for (int p4 = 0; p4 < 4; ++p4) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + p4 * 4);
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + n * (KC * VPL) + p4 * 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            acc[p4 * 4 + e][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], acc[p4 * 4 + e][n], 0, 0, 0);
-        }
+      for (int r = 0; r < 4; ++r) {
+        d[r][0] = *reinterpret_cast<const f32x2*>(rb + (kd * IY + r) * RX);
+        d[r][1] = *reinterpret_cast<const f32x2*>(rb + (kd * IY + r) * RX + 2);
       }
+    };
+    auto load_b = [&](int g, int slot) __attribute__((always_inline)) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        bq[slot][n] = *reinterpret_cast<const f32x4*>(ub + ((g >> 2) * NT + n) * (KC * 256) + b_lo[g & 3]);
+    };
+    // V = Bt d B on packed-fp32 adds: rows as register pairs (two columns at a time), then per row the column
+    // combinations (t0-t2, t1+t2) and (t2-t1, t1-t3) as one v_pk_add_f32 each (op_sel picks the halves, neg_* the
+    // signs) -- 16 vector instructions per patch instead of 32 adds plus the moves the compiler puts around them
+    auto transform = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        f32x2 t0, t1;
+        if (r == 0) { t0 = d[0][0] - d[2][0]; t1 = d[0][1] - d[2][1]; }
+        if (r == 1) { t0 = d[1][0] + d[2][0]; t1 = d[1][1] + d[2][1]; }
+        if (r == 2) { t0 = d[2][0] - d[1][0]; t1 = d[2][1] - d[1][1]; }
+        if (r == 3) { t0 = d[1][0] - d[3][0]; t1 = d[1][1] - d[3][1]; }
+        asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(vp[slot][r][0]) : "v"(t0), "v"(t1));
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]"
+            : "=v"(vp[slot][r][1]) : "v"(t1), "v"(t0));
+      }
+    };
+    load_patch(0);
+    load_b(0, 0);
+    transform(0);
+#ifdef ABL_NOMFMA
+    if (a.Cin == 12345)
+#endif
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {
+      const int kd = g >> 2, p4 = g & 3;
+      if (g + 1 < 12) load_b(g + 1, (g + 1) & 1);
+#ifndef ABL_NOXF
+      if (p4 == 0 && kd < 2) load_patch(kd + 1);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc[p4 * 4 + e][n] =
+              __builtin_amdgcn_mfma_f32_16x16x4f32(vp[kd & 1][p4][e >> 1][e & 1], bq[g & 1][n][e], acc[p4 * 4 + e][n], 0, 0, 0);
+#ifndef ABL_NOXF
+      if (p4 == 1 && kd < 2) transform((kd + 1) & 1);
+#else
+      if (p4 == 1 && kd < 2) for (int q = 0; q < 8; ++q) vp[(kd + 1) & 1][q >> 1][q & 1] = vp[kd & 1][q >> 1][q & 1];
+#endif
+      __builtin_amdgcn_sched_barrier(0);
     }
+  };
+  for (int c0 = 0; c0 < a.Cin; c0 += 2 * KC) {
+    chunk(c0, 0, vinA);
+    if (c0 + KC < a.Cin) chunk(c0 + KC, 1, vinB);
   }
 
-  // ---- epilogue: Y = At M A per tile, BN scale/bias, residual, activation.  A lane holds output channel j of
-  // tiles 4*kq .. 4*kq+3 = tile row kq>>1, tile columns (kq&1)*4 .. +3: 8 consecutive x of two output rows ----
+  // ---- epilogue: Y = At M A per tile, BN scale/bias, residual, activation.  M index m = tile (row m&1, column
+  // m>>1), so a lane (cout j, tiles 4*kq .. 4*kq+3) holds tile columns 2kq, 2kq+1 of both tile rows: 4 consecutive x
+  // of four output rows, and the four kq lanes of a channel write 64 contiguous bytes per row ----
   const int zo = z0 + wave;
-  const int yb = y0 + 2 * (kq >> 1), xb = x0 + (kq & 1) * 8;
-  const bool fast = a.fast_ok && x0 + TW <= a.W && y0 + TH <= a.H;
   if (zo >= a.D) return;
+#ifdef ABL_NOEPI
+  if (acc[0][0][0] + acc[5][1][2] + acc[15][1][3] + acc[9][0][1] != 123.456f) return;
+#endif
+  const int xb = x0 + 4 * kq;
+  const bool fast = a.fast_ok && x0 + TW <= a.W && y0 + TH <= a.H;
+  const float slope = a.act == DV_ACT_RELU ? 0.f : (a.act == DV_ACT_LEAKY ? 0.01f : 1.f);
+  const bool mish = a.act == DV_ACT_MISH;
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int co = co0 + n * 16 + j;
     if (co >= a.Cout) continue;
     const float sc = a.ch_scale ? a.ch_scale[co] : 1.f;
     const float bi = a.ch_bias ? a.ch_bias[co] : 0.f;
-    float yv[2][8];
+    const size_t cbase = (((size_t)b * a.Cout + co) * a.D + zo) * plane + (size_t)y0 * a.W + xb;
+    f32x4 rv[4];
+    if (fast && a.residual) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float s0[4], s1[4];
-#pragma unroll
-      for (int px = 0; px < 4; ++px) {
-        const float m0 = acc[px][n][i], m1 = acc[4 + px][n][i], m2 = acc[8 + px][n][i], m3 = acc[12 + px][n][i];
-        s0[px] = m0 + m1 + m2;
-        s1[px] = m1 - m2 - m3;
-      }
-      yv[0][2 * i] = s0[0] + s0[1] + s0[2];
-      yv[0][2 * i + 1] = s0[1] - s0[2] - s0[3];
-      yv[1][2 * i] = s1[0] + s1[1] + s1[2];
-      yv[1][2 * i + 1] = s1[1] - s1[2] - s1[3];
+      for (int r = 0; r < 4; ++r) rv[r] = *reinterpret_cast<const f32x4*>(a.residual + cbase + (size_t)r * a.W);
     }
-    const size_t cbase = (((size_t)b * a.Cout + co) * a.D + zo) * plane;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int yo = yb + r;
-      if (yo >= a.H) continue;
-      const size_t o = cbase + (size_t)yo * a.W + xb;
-      float v[8];
+    for (int tr = 0; tr < 2; ++tr) {       // tile row
+      float yv[2][4];                      // two output rows x 4 x
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = fmaf(yv[r][e], sc, bi);
-      if (fast) {
-        if (a.residual) {
-          const f32x4 r0 = *reinterpret_cast<const f32x4*>(a.residual + o);
-          const f32x4 r1 = *reinterpret_cast<const f32x4*>(a.residual + o + 4);
+      for (int tcx = 0; tcx < 2; ++tcx) {  // tile column 2kq + tcx = accumulator element i = tr + 2*tcx
+        const int i = tr + 2 * tcx;
+        float s0[4], s1[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+        for (int px = 0; px < 4; ++px) {
+          const float m0 = acc[px][n][i], m1 = acc[4 + px][n][i], m2 = acc[8 + px][n][i], m3 = acc[12 + px][n][i];
+          s0[px] = m0 + m1 + m2;
+          s1[px] = m1 - m2 - m3;
         }
-        f32x4 o0, o1;
+        yv[0][2 * tcx] = s0[0] + s0[1] + s0[2];
+        yv[0][2 * tcx + 1] = s0[1] - s0[2] - s0[3];
+        yv[1][2 * tcx] = s1[0] + s1[1] + s1[2];
+        yv[1][2 * tcx + 1] = s1[1] - s1[2] - s1[3];
+      }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { o0[e] = dv_act(v[e], a.act); o1[e] = dv_act(v[4 + e], a.act); }
-        *reinterpret_cast<f32x4*>(a.out + o) = o0;
-        *reinterpret_cast<f32x4*>(a.out + o + 4) = o1;
-      } else {
+      for (int r = 0; r < 2; ++r) {
+        const int yr = 2 * tr + r;
+        const size_t o = cbase + (size_t)yr * a.W;
+        if (fast) {
+          f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (xb + e < a.W) {
-            float u = v[e];
-            if (a.residual) u += a.residual[o + e];
-            a.out[o + e] = dv_act(u, a.act);
-          }
+          for (int e = 0; e < 4; ++e) v[e] = fmaf(yv[r][e], sc, bi);
+          if (a.residual) v += rv[yr];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = mish ? dv_act(v[e], DV_ACT_MISH) : fmaxf(v[e], v[e] * slope);
+          *reinterpret_cast<f32x4*>(a.out + o) = v;
+        } else if (y0 + yr < a.H) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (xb + e < a.W) {
+              float u = fmaf(yv[r][e], sc, bi);
+              if (a.residual) u += a.residual[o + e];
+              a.out[o + e] = dv_act(u, a.act);
+            }
+        }
       }
     }
   }

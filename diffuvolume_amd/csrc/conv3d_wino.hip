@@ -85,10 +85,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_wino_kernel(WinoArgs a) {
   const float* inb = a.in + (size_t)b * a.Cin * vol;
   const float* scb = (HAS_SCALE && a.in_scale) ? a.in_scale + (size_t)b * vol : nullptr;
 
-  // ---- raw staging plan: NS positions of the haloed brick per thread, the same for every channel ----
+  // ---- raw staging plan: NS positions of the haloed brick per thread, the same for every channel.  The loads
+  // are buffer loads (one descriptor per channel, built on the scalar unit): the lane part of the address is a
+  // 32-bit offset, and both the zero padding (offset 2^31 for positions outside the volume) and the channel tail
+  // (zero records) come out of the hardware range check instead of vector selects ----
   unsigned sob[NS];                 // byte offset in a channel volume
   int lro[NS];                      // float offset in a channel of the LDS brick
-  unsigned okmask = 0;
   float scl[HAS_SCALE ? NS : 1];
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
@@ -99,31 +101,31 @@ __global__ __launch_bounds__(256, 2) void conv3d_wino_kernel(WinoArgs a) {
     const bool ok = r < PRAW && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H &&
                     (unsigned)x < (unsigned)a.W;
     const unsigned sp = ok ? (unsigned)((z * a.H + y) * a.W + x) : 0u;
-    sob[i] = sp * 4u;
+    sob[i] = ok ? sp * 4u : 0x80000000u;
     lro[i] = r < PRAW ? (zz * IY + yy) * RX + xx : IX;      // lanes past the brick write a column no patch reads
-    okmask |= ok ? (1u << i) : 0u;
     if (HAS_SCALE) scl[i] = (ok && scb) ? scb[sp] : 1.f;
   }
+  const int vol_bytes = (int)(vol * sizeof(float));          // < 2^31 (checked by the host)
   float vinA[KC][NS], vinB[KC][NS];   // raw loads run two chunks ahead of their use: two register sets
   auto fetch_raw = [&](int c0, float (&vin)[KC][NS]) __attribute__((always_inline)) {
 #pragma unroll
     for (int cl = 0; cl < KC; ++cl) {
-      const int ch = (c0 + cl) < a.Cin ? c0 + cl : 0;
-      const char* src = reinterpret_cast<const char*>(inb + (size_t)ch * vol);
+      const bool cok = (c0 + cl) < a.Cin;
+      const uint64_t ba = reinterpret_cast<uint64_t>(inb + (size_t)(cok ? c0 + cl : 0) * vol);
+      const uint64_t bu = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ba) |
+                          ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ba >> 32)) << 32);
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(bu), 0,
+                                                        __builtin_amdgcn_readfirstlane(cok ? vol_bytes : 0), 0x00020000);
 #pragma unroll
-      for (int i = 0; i < NS; ++i) vin[cl][i] = *reinterpret_cast<const float*>(src + sob[i]);
+      for (int i = 0; i < NS; ++i)
+        vin[cl][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)sob[i], 0, 0));
     }
   };
   auto commit_raw = [&](int c0, float* rb, float (&vin)[KC][NS]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int cl = 0; cl < KC; ++cl) {
-      const bool cok = (c0 + cl) < a.Cin;
+    for (int cl = 0; cl < KC; ++cl)
 #pragma unroll
-      for (int i = 0; i < NS; ++i) {
-        const float v = (cok && ((okmask >> i) & 1u)) ? vin[cl][i] : 0.f;
-        rb[cl * RAWP + lro[i]] = HAS_SCALE ? v * scl[i] : v;
-      }
-    }
+      for (int i = 0; i < NS; ++i) rb[cl * RAWP + lro[i]] = HAS_SCALE ? vin[cl][i] * scl[i] : vin[cl][i];
   };
   // ---- weights: the packed chunk is the LDS image; LDS-DMA copies it in 1-KB pieces (16 cout rows x 4 position
   // quads), six per wave.  Lane l of a piece lands in 16-byte slot l, so the source quad is XOR-swizzled with the
@@ -370,7 +372,7 @@ extern "C" int dv_conv3d_wino_f32(const float* in, const float* wpacked, const f
   DV_REQUIRE_PTR(wpacked);
   DV_REQUIRE_PTR(out);
   DV_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0 && Cout > 0, DV_ERR_SHAPE);
-  DV_REQUIRE((size_t)D * H * W * sizeof(float) <= 0xffffffffull, DV_ERR_SHAPE);
+  DV_REQUIRE((size_t)D * H * W * sizeof(float) <= 0x7fffffffull, DV_ERR_SHAPE);   // 31-bit byte offsets in a channel
   DV_REQUIRE(act >= DV_ACT_NONE && act <= DV_ACT_LEAKY, DV_ERR_UNSUPPORTED);
   DV_REQUIRE(dv_aligned16(wpacked), DV_ERR_ALIGN);
   WinoArgs a;

@@ -14,7 +14,7 @@ Workload = BASELINE.json configs[1]: SceneFlow ACVNet+DiffuVolume, 960x540 frame
 GPU, 5 DDIM steps, fp32.  N>1: one process per GPU (torchrun), weak scaling.
 
 Prints ONE JSON line (rank 0): the driver contract plus `roofline` (dominant kernel: the
-fp32-MFMA implicit-GEMM conv, HIP-event timed inside the timed region) and `cpu_baseline`
+fp32-MFMA Winograd conv of the 32-channel layers, HIP-event timed inside the timed region) and `cpu_baseline`
 (the CPU oracle on a bounded sample of the same workload, rank 0, N=1 only).
 """
 from __future__ import annotations
@@ -37,7 +37,8 @@ ALGO_BYTES_PER_PAIR = 23.2e9      # ideal-fusion fp32 HBM bytes of 
 ALGO_FLOP_PER_PAIR = 3.76e12
 
 
-DOMINANT_KERNEL = "conv3d_mfma_kernel<Geo<3, 1, 2, 3, 4, 4, 4, 2>, false>"
+DOMINANT_KERNEL = "conv3d_wino_kernel<false>"
+WINO_MULT_REDUCTION = 2.25        # F(2x2,3x3) in-plane: 16 multiplies per 2x2 outputs and depth tap instead of 36
 
 
 def pmc_traffic(kernel):
@@ -256,11 +257,18 @@ def main():
         dom = ks.get("conv3d_k3s1_co32")
         if dom:
             ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
+            # `achieved` is the contract's figure: ALGORITHMIC flop (direct-convolution count) per second.
+            # The kernel is the Winograd F(2x2,3x3) form, which issues 2.25x fewer MFMA flops than that count, so
+            # `frac` can exceed 1; `mfma_issued` prices the matrix pipe with the flops actually issued.
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": pmc_traffic(DOMINANT_KERNEL),
-                               "kernel": DOMINANT_KERNEL + " (the 32->32 k3 convs of dres0/dres1/classif2)",
+                               "kernel": DOMINANT_KERNEL + " (the 32->32 k3 convs of dres0/dres1/classif2; Winograd "
+                                         "F(2x2,3x3) in-plane, depth taps direct, v_mfma_f32_16x16x4_f32)",
                                "launches": dom["launches"], "avg_ms": dom["avg_ms"],
-                               "algorithmic_gflop_per_launch": dom["flops"] / dom["launches"] / 1e9}
+                               "algorithmic_gflop_per_launch": dom["flops"] / dom["launches"] / 1e9,
+                               "mfma_issued": {"tflops": ach / WINO_MULT_REDUCTION,
+                                               "frac": ach / WINO_MULT_REDUCTION / PEAK_MFMA_F32_TFLOPS,
+                                               "note": "algorithmic flop / 2.25 = multiplies the Winograd form executes"}}
         out["kernels_ms_per_step"] = {k: round(v["total_ms"] / a.steps, 3) for k, v in sorted(ks.items())}
         out["kernels_tflops_or_gbs"] = {
             k: (round(v["flops"] / v["total_ms"] / 1e9, 2) if k.startswith(("conv", "deconv", "window"))

@@ -254,18 +254,29 @@ def main():
     }
     if rank == 0 and timer is not None:
         ks = timer.summary()
-        dom = ks.get("conv3d_k3s1_co32")
-        if dom:
-            ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
-            # `achieved` is the contract's figure: ALGORITHMIC flop (direct-convolution count) per second.
-            # The kernel is the Winograd F(2x2,3x3) form, which issues 2.25x fewer MFMA flops than that count, so
-            # `frac` can exceed 1; `mfma_issued` prices the matrix pipe with the flops actually issued.
+        # dominant kernel = conv3d_wino_kernel<false>: every 3x3x3 stride-1 layer without the noise prologue
+        # (32->32, 64->64, 128->128; the filter layer is the <true> instantiation).  All its launches are pooled so
+        # that `avg_ms` is the same average rocprofv3 --stats reports for that kernel name.
+        fam = {k: v for k, v in ks.items() if k in ("conv3d_k3s1_co32", "conv3d_k3s1_co64", "conv3d_k3s1_co128")}
+        if fam:
+            flops = sum(v["flops"] for v in fam.values())
+            ms = sum(v["total_ms"] for v in fam.values())
+            launches = sum(v["launches"] for v in fam.values())
+            ach = flops / (ms * 1e-3) / 1e12
+            # `achieved` is the contract's figure: ALGORITHMIC flop (direct-convolution count, SURVEY 8d: 2*27*Cin*Cout
+            # per output voxel) per second.  The kernel is the Winograd F(2x2,3x3) form, which issues 2.25x fewer MFMA
+            # flops than that count, so `frac` can exceed 1; `mfma_issued` prices the matrix pipe with the flops
+            # actually issued.
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": pmc_traffic(DOMINANT_KERNEL),
-                               "kernel": DOMINANT_KERNEL + " (the 32->32 k3 convs of dres0/dres1/classif2; Winograd "
-                                         "F(2x2,3x3) in-plane, depth taps direct, v_mfma_f32_16x16x4_f32)",
-                               "launches": dom["launches"], "avg_ms": dom["avg_ms"],
-                               "algorithmic_gflop_per_launch": dom["flops"] / dom["launches"] / 1e9,
+                               "kernel": DOMINANT_KERNEL + " (all 3x3x3 stride-1 layers of dres0/dres1/hourglass/classif2 "
+                                         "except the filter layer; Winograd F(2x2,3x3) in-plane, depth taps direct, "
+                                         "v_mfma_f32_16x16x4_f32)",
+                               "launches": launches, "avg_ms": ms / launches,
+                               "algorithmic_gflop_per_launch": flops / launches / 1e9,
+                               "by_layer": {k: {"launches": v["launches"], "avg_ms": v["avg_ms"],
+                                                "algorithmic_tflops": v["flops"] / v["total_ms"] / 1e9}
+                                            for k, v in sorted(fam.items())},
                                "mfma_issued": {"tflops": ach / WINO_MULT_REDUCTION,
                                                "frac": ach / WINO_MULT_REDUCTION / PEAK_MFMA_F32_TFLOPS,
                                                "note": "algorithmic flop / 2.25 = multiplies the Winograd form executes"}}

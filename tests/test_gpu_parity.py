@@ -112,17 +112,27 @@ def _bn_tuple(sd, p):
     return (sd[p + ".weight"], sd[p + ".bias"], sd[p + ".running_mean"], sd[p + ".running_var"])
 
 
+# "f32" runs the 3x3x3 stride-1 layers on the Winograd kernel (csrc/conv3d_wino.hip), "f32_direct" everything on the
+# direct implicit GEMM (csrc/conv3d.hip); both are held to the same bars
+PRECISIONS = ["f32", "f32_direct"]
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("tag", ["c3s1", "c3s2", "c1s1", "c3s1_wide", "c3s1_one"])
-def test_conv_golden(tag):
+def test_conv_golden(tag, precision):
     from diffuvolume_amd.acv_ddim import _cb3
     g = load_golden(f"layer_{tag}")
     k, s = g["k"], g["stride"]
+    if precision == "f32_direct" and not (k == 3 and s == 1 and g["cout"] > 1):
+        pytest.skip("same kernel as 'f32' for this layer")
     sd = synth_state_dict(_cb3(g["cin"], g["cout"], k, s, (k - 1) // 2).state_dict(), seed=g["seed"])
-    plan = S.Conv3dPlan(dev(sd["0.weight"]), tuple(dev(t) for t in _bn_tuple(sd, "1")), stride=s, act=S.ACT_NONE)
+    plan = S.Conv3dPlan(dev(sd["0.weight"]), tuple(dev(t) for t in _bn_tuple(sd, "1")), stride=s, act=S.ACT_NONE,
+                        precision=precision)
     y = plan(dev(g["x"]))
     assert y.shape == g["y"].shape
     assert rel_err(y, g["y"]) < 1e-5
-    plan = S.Conv3dPlan(dev(sd["0.weight"]), tuple(dev(t) for t in _bn_tuple(sd, "1")), stride=s, act=S.ACT_RELU)
+    plan = S.Conv3dPlan(dev(sd["0.weight"]), tuple(dev(t) for t in _bn_tuple(sd, "1")), stride=s, act=S.ACT_RELU,
+                        precision=precision)
     assert rel_err(plan(dev(g["x"])), g["y_relu"]) < 1e-5
 
 
@@ -132,8 +142,11 @@ def test_conv_golden(tag):
                                  (40, 32, 3, 1, (1, 4, 4, 32)), (32, 1, 3, 1, (1, 8, 8, 32)),
                                  (32, 32, 1, 1, (1, 4, 8, 16)), (64, 64, 1, 1, (1, 4, 6, 18)),
                                  (32, 32, 3, 1, (1, 4, 5, 30)), (8, 16, 3, 2, (1, 8, 9, 13))])
-def test_conv_oracle(cfg):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_conv_oracle(cfg, precision):
     cin, cout, k, s, dims = cfg
+    if precision == "f32_direct" and not (k == 3 and s == 1 and cout > 1):
+        pytest.skip("same kernel as 'f32' for this layer")
     g = _gen(7, str(cfg))
     x = torch.randn(dims[0], cin, *dims[1:], generator=g)
     w = torch.randn(cout, cin, k, k, k, generator=g) * (2.0 / (k ** 3 * cin)) ** 0.5
@@ -141,7 +154,7 @@ def test_conv_oracle(cfg):
           torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5)
     y_ref = torch.nn.functional.batch_norm(torch.nn.functional.conv3d(x, w, None, s, (k - 1) // 2),
                                            bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5)
-    plan = S.Conv3dPlan(dev(w), tuple(dev(t) for t in bn), stride=s, act=S.ACT_NONE)
+    plan = S.Conv3dPlan(dev(w), tuple(dev(t) for t in bn), stride=s, act=S.ACT_NONE, precision=precision)
     assert rel_err(plan(dev(x)), y_ref) < 1e-5
     # fused prologue scale, residual and ReLU (acv_ddim.py:260-262)
     if s == 1:
@@ -149,19 +162,67 @@ def test_conv_oracle(cfg):
         res = torch.randn(y_ref.shape, generator=g)
         y2 = torch.nn.functional.batch_norm(torch.nn.functional.conv3d(x * scale.unsqueeze(1), w, None, s, (k - 1) // 2),
                                             bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5)
-        plan = S.Conv3dPlan(dev(w), tuple(dev(t) for t in bn), stride=s, act=S.ACT_RELU)
+        plan = S.Conv3dPlan(dev(w), tuple(dev(t) for t in bn), stride=s, act=S.ACT_RELU, precision=precision)
         out = plan(dev(x), in_scale=dev(scale), residual=dev(res))
         assert rel_err(out, torch.relu(y2 + res)) < 1e-5
 
 
+@pytest.mark.parametrize("cfg", [(5, 20, (2, 5, 7, 19)), (3, 40, (1, 3, 3, 3)), (33, 33, (1, 1, 2, 17)),
+                                 (4, 32, (1, 9, 5, 6)), (7, 70, (1, 2, 9, 33)), (12, 32, (1, 4, 4, 16))])
+def test_conv_winograd_edges(cfg):
+    """Winograd kernel on shapes that leave every kind of partial tile: odd H / W (half 2x2 output tiles), depth not a
+    multiple of the 4 planes of a block, channel tails on both sides (Cin % 4, Cout % 32), rows that are not
+    16-byte aligned (scalar store path), with residual and the `volume * noise` prologue."""
+    cin, cout, dims = cfg
+    g = _gen(31, str(cfg))
+    x = torch.randn(dims[0], cin, *dims[1:], generator=g)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5
+    scale = torch.rand(dims[0], *dims[1:], generator=g)
+    res = torch.randn(dims[0], cout, *dims[1:], generator=g)
+    ref = torch.nn.functional.leaky_relu(
+        torch.nn.functional.conv3d(x.double() * scale.double().unsqueeze(1), w.double(), None, 1, 1) + res.double(), 0.01)
+    plan = S.Conv3dPlan(dev(w), None, stride=1, act=S.ACT_LEAKY, precision="f32")
+    assert plan.wino
+    out = plan(dev(x), in_scale=dev(scale), residual=dev(res))
+    assert rel_err(out, ref.float()) < 1e-5
+    direct = S.Conv3dPlan(dev(w), None, stride=1, act=S.ACT_LEAKY, precision="f32_direct")(dev(x), in_scale=dev(scale),
+                                                                                           residual=dev(res))
+    torch.testing.assert_close(out, direct, atol=2e-5, rtol=1e-5)
+
+
+def test_conv_winograd_c_abi():
+    """dv_conv3d_wino_* straight through ctypes (the drop-in boundary), against torch's fp64 convolution."""
+    from diffuvolume_amd import _lib
+    lib = _lib.load()
+    g = _gen(32, "abi")
+    x, w = torch.randn(1, 8, 5, 6, 20, generator=g), torch.randn(16, 8, 3, 3, 3, generator=g) * 0.1
+    xd, wd = dev(x), dev(w)
+    n = lib.dv_conv3d_wino_packed_floats(8, 16)
+    assert n == 2 * 1 * 6144
+    wp = torch.empty(n, device=DEV)
+    out = torch.empty(1, 16, 5, 6, 20, device=DEV)
+    assert lib.dv_conv3d_wino_pack_weights_f32(wd.data_ptr(), wp.data_ptr(), 8, 16, _lib.stream_ptr()) == 0
+    rc = lib.dv_conv3d_wino_f32(xd.data_ptr(), wp.data_ptr(), None, None, None, None, out.data_ptr(), 1, 8, 5, 6, 20, 16,
+                                S.ACT_NONE, _lib.stream_ptr())
+    assert rc == 0
+    ref = torch.nn.functional.conv3d(x.double(), w.double(), None, 1, 1).float()
+    assert rel_err(out, ref) < 1e-5
+    # argument checks: null pointers and empty shapes are refused, nothing is launched
+    assert lib.dv_conv3d_wino_f32(None, wp.data_ptr(), None, None, None, None, out.data_ptr(), 1, 8, 5, 6, 20, 16, 0,
+                                  _lib.stream_ptr()) != 0
+    assert lib.dv_conv3d_wino_f32(xd.data_ptr(), wp.data_ptr(), None, None, None, None, out.data_ptr(), 0, 8, 5, 6, 20, 16,
+                                  0, _lib.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("act", [S.ACT_MISH, S.ACT_LEAKY])
-def test_conv_activations(act):
+def test_conv_activations(act, precision):
     g = _gen(8, "act")
     x = torch.randn(1, 16, 4, 6, 16, generator=g)
     w = torch.randn(16, 16, 3, 3, 3, generator=g) * 0.1
     y = torch.nn.functional.conv3d(x, w, None, 1, 1)
     ref = y * torch.tanh(torch.nn.functional.softplus(y)) if act == S.ACT_MISH else torch.nn.functional.leaky_relu(y, 0.01)
-    out = S.Conv3dPlan(dev(w), None, stride=1, act=act)(dev(x))
+    out = S.Conv3dPlan(dev(w), None, stride=1, act=act, precision=precision)(dev(x))
     torch.testing.assert_close(out.cpu(), ref, atol=2e-5, rtol=1e-4)
 
 

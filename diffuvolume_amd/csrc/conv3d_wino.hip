@@ -25,20 +25,26 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// MTW = M-tiles (planes) per wave: 1 -> 4 planes per block, 128 accumulator registers, two blocks per CU;
+// 2 -> 8 planes per block (wave w owns planes w and w+4), 256 accumulator registers (the AGPR half of the
+// 512-register file), one block per CU: every B fragment feeds two MFMAs, half the weight DMA / barriers / blocks.
+template <int MTW_>
+struct WG {
+  static constexpr int MTW = MTW_;
+  static constexpr int KC = 4, NT = 2, TD = 4 * MTW, TH = 4, TW = 16;
+  static constexpr int IZ = TD + 2, IY = TH + 2, IX = TW + 2;
+  static constexpr int PRAW = IZ * IY * IX;          // raw positions per channel (648 / 1080)
+  // raw brick [c][z][y][RX]: row stride 24 and a channel stride = 32 mod 64 put the 16 tiles x 2 channels a 32-lane
+  // half reads with one ds_read_b64 (tile columns 2 floats apart, tile rows 2*RX = 48 apart) on 64 distinct banks
+  static constexpr int RX = 24;
+  static constexpr int RAWP = IZ * IY * RX;
+  static constexpr int RAW_FLOATS = KC * RAWP;
+  static constexpr int NS = (PRAW + 255) / 256;
+  static_assert(RAWP % 64 == 32, "bank plan of the patch reads");
+};
 namespace wg {
-constexpr int KC = 4, NT = 2, TD = 4, TH = 4, TW = 16;
-constexpr int IZ = TD + 2, IY = TH + 2, IX = TW + 2;
-constexpr int PRAW = IZ * IY * IX;          // 648 raw positions per channel
-// raw brick [c][z][y][RX]: row stride 24 and channel stride 864 (= 32 mod 64) put the 16 tiles x 2 channels a
-// 32-lane half reads with one ds_read_b64 (tile columns 2 floats apart, tile rows 2*RX = 48 apart) on 64 distinct banks
-constexpr int RX = 24;
-constexpr int RAWP = IZ * IY * RX;
-constexpr int RAW_FLOATS = KC * RAWP;
-constexpr int U_CHUNK = 3 * NT * KC * 16 * 16;   // packed floats per (chunk, co block) = the LDS image, 24 KB
-constexpr int NS = (PRAW + 255) / 256;
-static_assert(RAWP % 64 == 32, "bank plan of the patch reads");
-static_assert((RAW_FLOATS + U_CHUNK) * 2 * 4 * 2 <= 160 * 1024, "two blocks per CU, both stages double-buffered");
-}  // namespace wg
+constexpr int U_CHUNK = 3 * 2 * 4 * 16 * 16;   // packed floats per (chunk, co block) = the LDS image, 24 KB
+}
 
 struct WinoArgs {
   const float* in;
@@ -54,9 +60,12 @@ struct WinoArgs {
   int fast_ok;           // W % 4 == 0, 16-byte aligned pointers
 };
 
-template <bool HAS_SCALE>
-__global__ __launch_bounds__(256, 2) void conv3d_wino_kernel(WinoArgs a) {
-  using namespace wg;
+template <bool HAS_SCALE, int MTW>
+__global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(WinoArgs a) {
+  using G = WG<MTW>;
+  constexpr int KC = G::KC, NT = G::NT, TD = G::TD, TH = G::TH, TW = G::TW, IY = G::IY, IX = G::IX, PRAW = G::PRAW;
+  constexpr int RX = G::RX, RAWP = G::RAWP, RAW_FLOATS = G::RAW_FLOATS, NS = G::NS, U_CHUNK = wg::U_CHUNK;
+  static_assert((2 * U_CHUNK + 2 * RAW_FLOATS) * 4 * (MTW == 1 ? 2 : 1) <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(1024))) float smem[2 * U_CHUNK + 2 * RAW_FLOATS];
   float* u_s = smem;
   float* raw_s = smem + 2 * U_CHUNK;
@@ -74,11 +83,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_wino_kernel(WinoArgs a) {
   const int b = t / a.nco;
   const int x0 = tx * TW, y0 = ty * TH, z0 = tz * TD, co0 = tc * 32;
 
-  f32x4 acc[16][NT];
+  f32x4 acc[MTW][16][NT];
 #pragma unroll
-  for (int p = 0; p < 16; ++p)
+  for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-    for (int n = 0; n < NT; ++n) acc[p][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[mt][p][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const size_t plane = (size_t)a.H * a.W;
   const size_t vol = (size_t)a.D * plane;
@@ -143,7 +154,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_wino_kernel(WinoArgs a) {
   };
 
   // this lane's 4x4 patch: tile (row j&1, column j>>1) of plane wave+kd, channel kq;  B rows (kq, j)
-  const int patch_lo = kq * RAWP + (wave * IY + 2 * (j & 1)) * RX + 2 * (j >> 1);
+  int patch_lo[MTW];
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt) patch_lo[mt] = kq * RAWP + ((wave + 4 * mt) * IY + 2 * (j & 1)) * RX + 2 * (j >> 1);
   int b_lo[4];
 #pragma unroll
   for (int p4 = 0; p4 < 4; ++p4) b_lo[p4] = (kq * 16 + j) * 16 + ((p4 ^ ((j >> 2) & 3)) * 4);
@@ -155,37 +168,33 @@ __global__ __launch_bounds__(256, 2) void conv3d_wino_kernel(WinoArgs a) {
   if (2 * KC < a.Cin) fetch_raw(2 * KC, vinB);
   // one chunk: `vin` holds the raw brick of chunk c0+KC on entry and that of chunk c0+3*KC on exit
   auto chunk = [&](int c0, int cur, float (&vin)[KC][NS]) __attribute__((always_inline)) {
-    // this chunk's weights (DMA, issued one chunk ago) have to be in LDS; the raw loads issued after them (12 per
+    // this chunk's weights (DMA, issued one chunk ago) have to be in LDS; the raw loads issued after them (KC*NS per
     // thread, for chunk c0+2*KC) may stay in flight.  After the barrier every wave is done with the other pair of
     // buffers and this chunk's raw brick is complete.
-#ifndef ABL_NOSYNC
-    if (c0 + 2 * KC < a.Cin) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    if (c0 + 2 * KC < a.Cin) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KC * NS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-#endif
     if (c0 + KC < a.Cin) {
-#ifndef ABL_NOU
       dma_u(c0 + KC, u_s + (cur ^ 1) * U_CHUNK);
-#endif
-#ifndef ABL_NORAW
       commit_raw(c0 + KC, raw_s + (cur ^ 1) * RAW_FLOATS, vin);
       if (c0 + 3 * KC < a.Cin) fetch_raw(c0 + 3 * KC, vin);
-#endif
       __builtin_amdgcn_sched_barrier(0);
     }
-    const float* rb = raw_s + cur * RAW_FLOATS + patch_lo;
+    const float* rb = raw_s + cur * RAW_FLOATS;
     const float* ub = u_s + cur * U_CHUNK;
-    // MFMA stream: 12 groups (kd, position quad) of 8 MFMAs.  The B fragments of group g+1, the raw patch of the
-    // next plane and its transform are issued in the shadow of group g (sched_barrier pins that order).
-    f32x2 d[4][2];
+    // MFMA stream: 12 groups (kd, position quad) of 8*MTW MFMAs.  The B fragments of group g+1, the raw patches of
+    // the next plane(s) and their transform are issued in the shadow of group g (sched_barrier pins that order).
+    f32x2 d[MTW][4][2];
     f32x4 bq[2][NT];
-    f32x2 vp[2][4][2];      // V of the current / next plane: [row][column pair]
+    f32x2 vp[MTW][2][4][2];      // V of the current / next plane: [row][column pair]
     auto load_patch = [&](int kd) __attribute__((always_inline)) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        d[r][0] = *reinterpret_cast<const f32x2*>(rb + (kd * IY + r) * RX);
-        d[r][1] = *reinterpret_cast<const f32x2*>(rb + (kd * IY + r) * RX + 2);
-      }
+      for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          d[mt][r][0] = *reinterpret_cast<const f32x2*>(rb + patch_lo[mt] + (kd * IY + r) * RX);
+          d[mt][r][1] = *reinterpret_cast<const f32x2*>(rb + patch_lo[mt] + (kd * IY + r) * RX + 2);
+        }
     };
     auto load_b = [&](int g, int slot) __attribute__((always_inline)) {
 #pragma unroll
@@ -197,62 +206,70 @@ __global__ __launch_bounds__(256, 2) void conv3d_wino_kernel(WinoArgs a) {
     // signs) -- 16 vector instructions per patch instead of 32 adds plus the moves the compiler puts around them
     auto transform = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        f32x2 t0, t1;
-        if (r == 0) { t0 = d[0][0] - d[2][0]; t1 = d[0][1] - d[2][1]; }
-        if (r == 1) { t0 = d[1][0] + d[2][0]; t1 = d[1][1] + d[2][1]; }
-        if (r == 2) { t0 = d[2][0] - d[1][0]; t1 = d[2][1] - d[1][1]; }
-        if (r == 3) { t0 = d[1][0] - d[3][0]; t1 = d[1][1] - d[3][1]; }
-        asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(vp[slot][r][0]) : "v"(t0), "v"(t1));
-        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]"
-            : "=v"(vp[slot][r][1]) : "v"(t1), "v"(t0));
-      }
+      for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          f32x2 t0, t1;
+          if (r == 0) { t0 = d[mt][0][0] - d[mt][2][0]; t1 = d[mt][0][1] - d[mt][2][1]; }
+          if (r == 1) { t0 = d[mt][1][0] + d[mt][2][0]; t1 = d[mt][1][1] + d[mt][2][1]; }
+          if (r == 2) { t0 = d[mt][2][0] - d[mt][1][0]; t1 = d[mt][2][1] - d[mt][1][1]; }
+          if (r == 3) { t0 = d[mt][1][0] - d[mt][3][0]; t1 = d[mt][1][1] - d[mt][3][1]; }
+          asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(vp[mt][slot][r][0]) : "v"(t0), "v"(t1));
+          asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]"
+              : "=v"(vp[mt][slot][r][1]) : "v"(t1), "v"(t0));
+        }
     };
     load_patch(0);
     load_b(0, 0);
     transform(0);
-#ifdef ABL_NOMFMA
-    if (a.Cin == 12345)
-#endif
 #pragma unroll
     for (int g = 0; g < 12; ++g) {
       const int kd = g >> 2, p4 = g & 3;
       if (g + 1 < 12) load_b(g + 1, (g + 1) & 1);
-#ifndef ABL_NOXF
       if (p4 == 0 && kd < 2) load_patch(kd + 1);
-#endif
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int n = 0; n < NT; ++n)
+      for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          acc[p4 * 4 + e][n] =
-              __builtin_amdgcn_mfma_f32_16x16x4f32(vp[kd & 1][p4][e >> 1][e & 1], bq[g & 1][n][e], acc[p4 * 4 + e][n], 0, 0, 0);
-#ifndef ABL_NOXF
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[mt][p4 * 4 + e][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[mt][kd & 1][p4][e >> 1][e & 1], bq[g & 1][n][e],
+                                                                          acc[mt][p4 * 4 + e][n], 0, 0, 0);
       if (p4 == 1 && kd < 2) transform((kd + 1) & 1);
-#else
-      if (p4 == 1 && kd < 2) for (int q = 0; q < 8; ++q) vp[(kd + 1) & 1][q >> 1][q & 1] = vp[kd & 1][q >> 1][q & 1];
-#endif
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  for (int c0 = 0; c0 < a.Cin; c0 += 2 * KC) {
-    chunk(c0, 0, vinA);
-    if (c0 + KC < a.Cin) chunk(c0 + KC, 1, vinB);
+  if constexpr (MTW == 1) {
+    for (int c0 = 0; c0 < a.Cin; c0 += 2 * KC) {
+      chunk(c0, 0, vinA);
+      if (c0 + KC < a.Cin) chunk(c0 + KC, 1, vinB);
+    }
+  } else {
+    // one call site: with 256 accumulators the register allocator spills thousands of registers around a second
+    // copy of the chunk body; the two raw register sets are swapped instead (KC*NS moves per chunk)
+    int cur = 0;
+#pragma unroll 1
+    for (int c0 = 0; c0 < a.Cin; c0 += KC, cur ^= 1) {
+      chunk(c0, cur, vinA);
+#pragma unroll
+      for (int cl = 0; cl < KC; ++cl)
+#pragma unroll
+        for (int i = 0; i < NS; ++i) { const float tmp = vinA[cl][i]; vinA[cl][i] = vinB[cl][i]; vinB[cl][i] = tmp; }
+    }
   }
 
   // ---- epilogue: Y = At M A per tile, BN scale/bias, residual, activation.  M index m = tile (row m&1, column
   // m>>1), so a lane (cout j, tiles 4*kq .. 4*kq+3) holds tile columns 2kq, 2kq+1 of both tile rows: 4 consecutive x
   // of four output rows, and the four kq lanes of a channel write 64 contiguous bytes per row ----
-  const int zo = z0 + wave;
-  if (zo >= a.D) return;
-#ifdef ABL_NOEPI
-  if (acc[0][0][0] + acc[5][1][2] + acc[15][1][3] + acc[9][0][1] != 123.456f) return;
-#endif
   const int xb = x0 + 4 * kq;
   const bool fast = a.fast_ok && x0 + TW <= a.W && y0 + TH <= a.H;
   const float slope = a.act == DV_ACT_RELU ? 0.f : (a.act == DV_ACT_LEAKY ? 0.01f : 1.f);
   const bool mish = a.act == DV_ACT_MISH;
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt) {
+  const int zo = z0 + wave + 4 * mt;
+  if (zo >= a.D) continue;
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int co = co0 + n * 16 + j;
@@ -274,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wino_kernel(WinoArgs a) {
         float s0[4], s1[4];
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
-          const float m0 = acc[px][n][i], m1 = acc[4 + px][n][i], m2 = acc[8 + px][n][i], m3 = acc[12 + px][n][i];
+          const float m0 = acc[mt][px][n][i], m1 = acc[mt][4 + px][n][i], m2 = acc[mt][8 + px][n][i], m3 = acc[mt][12 + px][n][i];
           s0[px] = m0 + m1 + m2;
           s1[px] = m1 - m2 - m3;
         }
@@ -307,6 +324,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wino_kernel(WinoArgs a) {
       }
     }
   }
+}
 }
 
 // U = G g Gt per (cout, cin, kd);  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
@@ -380,13 +398,20 @@ extern "C" int dv_conv3d_wino_f32(const float* in, const float* wpacked, const f
   a.residual = residual; a.out = out;
   a.B = B; a.Cin = Cin; a.D = D; a.H = H; a.W = W; a.Cout = Cout; a.act = act;
   a.fast_ok = (W % 4 == 0) && dv_aligned16(out) && (!residual || dv_aligned16(residual));
-  a.ntx = cdiv(W, wg::TW); a.nty = cdiv(H, wg::TH); a.ntz = cdiv(D, wg::TD); a.nco = cdiv(Cout, 32);
-  const long long blocks = (long long)B * a.nco * a.ntz * a.nty * a.ntx;
-  if (blocks <= 0 || blocks > 0x7fffffffLL) return DV_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
-  if (in_scale)
-    hipLaunchKernelGGL(conv3d_wino_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL(conv3d_wino_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
-  return dv_launch_status();
+  auto launch = [&](auto mtw) {
+    constexpr int MTW = decltype(mtw)::value;
+    using G = WG<MTW>;
+    a.ntx = cdiv(W, G::TW); a.nty = cdiv(H, G::TH); a.ntz = cdiv(D, G::TD); a.nco = cdiv(Cout, 32);
+    const long long blocks = (long long)B * a.nco * a.ntz * a.nty * a.ntx;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return (int)DV_ERR_SHAPE;
+    if (in_scale)
+      hipLaunchKernelGGL((conv3d_wino_kernel<true, MTW>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((conv3d_wino_kernel<false, MTW>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return dv_launch_status();
+  };
+  // MTW = 2 (one wave per SIMD on the 512-register file, two planes per wave) is correct but measured 4.25 vs 3.09 ms
+  // on the 32->32 layer: with a single wave per SIMD the LDS / barrier latencies of every chunk are exposed.
+  return launch(std::integral_constant<int, 1>{});
 }

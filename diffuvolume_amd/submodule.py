@@ -26,10 +26,10 @@ _CONV_PRECISION = None
 
 
 def set_default_conv_precision(precision=None) -> None:
-    """Override DV_CONV_PRECISION for plans built from now on ('f32', 'f16x3' or None = environment)."""
+    """Override DV_CONV_PRECISION for plans built from now on ('f32', 'f32_direct', 'f16x3' or None = environment)."""
     global _CONV_PRECISION
-    if precision not in (None, "f32", "f16x3"):
-        raise ValueError("precision must be 'f32', 'f16x3' or None")
+    if precision not in (None, "f32", "f32_direct", "f16x3"):
+        raise ValueError("precision must be 'f32', 'f32_direct', 'f16x3' or None")
     _CONV_PRECISION = precision
 
 
@@ -55,9 +55,10 @@ def check_split_overflow(device) -> None:
 
 
 def default_conv_precision() -> str:
-    """'f32' = exact-fp32 MFMA everywhere (default); 'f16x3' = the split-fp16 kernel for the 3x3x3
-    stride-1 layers it covers (csrc/conv3d_f16x3.hip; inputs must stay below 2.6e5 in magnitude).
-    Set with DV_CONV_PRECISION, set_default_conv_precision() or per plan."""
+    """'f32' = fp32 MFMA everywhere, the 3x3x3 stride-1 layers in the Winograd F(2x2,3x3) form
+    (csrc/conv3d_wino.hip; default); 'f32_direct' = fp32 MFMA with direct taps everywhere (csrc/conv3d.hip);
+    'f16x3' = the split-fp16 kernel for the 3x3x3 stride-1 layers it covers (csrc/conv3d_f16x3.hip; inputs must
+    stay below 2.6e5 in magnitude).  Set with DV_CONV_PRECISION, set_default_conv_precision() or per plan."""
     import os
     return _CONV_PRECISION or os.environ.get("DV_CONV_PRECISION", "f32")
 

@@ -146,7 +146,7 @@ for i in range(n):
     res = torch.randn(b, cout, d, h, w, device=dev)
     bnp = bn(cout)
     ref = torch.relu(F.batch_norm(F.conv3d(x * sc.unsqueeze(1), wt, None, 1, 1), bnp[2], bnp[3], bnp[0], bnp[1], False, 0.0, 1e-5) + res)
-    for prec in ("f32", "f16x3"):
+    for prec in ("f32", "f32_direct", "f16x3"):
         out = S.Conv3dPlan(wt, bnp, stride=1, act=S.ACT_RELU, precision=prec)(x, in_scale=sc, residual=res); torch.cuda.synchronize()
         if rel(out, ref) > 2e-5:
             bad3 += 1; print("conv3d", prec, "FAIL", (cin, cout, b, d, h, w), rel(out, ref))

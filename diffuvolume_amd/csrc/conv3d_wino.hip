@@ -117,26 +117,29 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
     if (HAS_SCALE) scl[i] = (ok && scb) ? scb[sp] : 1.f;
   }
   const int vol_bytes = (int)(vol * sizeof(float));          // < 2^31 (checked by the host)
-  float vinA[KC][NS], vinB[KC][NS];   // raw loads run two chunks ahead of their use: two register sets
-  auto fetch_raw = [&](int c0, float (&vin)[KC][NS]) __attribute__((always_inline)) {
+  float vin[KC][NS];                  // raw brick of the next chunk, refilled for the one after as soon as it is in LDS
+  auto fetch_raw_cl = [&](int c0, int cl) __attribute__((always_inline)) {
+    const bool cok = (c0 + cl) < a.Cin;
+    const uint64_t ba = reinterpret_cast<uint64_t>(inb + (size_t)(cok ? c0 + cl : 0) * vol);
+    const uint64_t bu = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ba) |
+                        ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ba >> 32)) << 32);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(bu), 0,
+                                                      __builtin_amdgcn_readfirstlane(cok ? vol_bytes : 0), 0x00020000);
 #pragma unroll
-    for (int cl = 0; cl < KC; ++cl) {
-      const bool cok = (c0 + cl) < a.Cin;
-      const uint64_t ba = reinterpret_cast<uint64_t>(inb + (size_t)(cok ? c0 + cl : 0) * vol);
-      const uint64_t bu = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ba) |
-                          ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ba >> 32)) << 32);
-      const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(bu), 0,
-                                                        __builtin_amdgcn_readfirstlane(cok ? vol_bytes : 0), 0x00020000);
-#pragma unroll
-      for (int i = 0; i < NS; ++i)
-        vin[cl][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)sob[i], 0, 0));
-    }
+    for (int i = 0; i < NS; ++i)
+      vin[cl][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)sob[i], 0, 0));
   };
-  auto commit_raw = [&](int c0, float* rb, float (&vin)[KC][NS]) __attribute__((always_inline)) {
+  auto fetch_raw = [&](int c0) __attribute__((always_inline)) {
 #pragma unroll
-    for (int cl = 0; cl < KC; ++cl)
+    for (int cl = 0; cl < KC; ++cl) fetch_raw_cl(c0, cl);
+  };
+  auto commit_raw_cl = [&](int cl, float* rb) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < NS; ++i) rb[cl * RAWP + lro[i]] = HAS_SCALE ? vin[cl][i] * scl[i] : vin[cl][i];
+    for (int i = 0; i < NS; ++i) rb[cl * RAWP + lro[i]] = HAS_SCALE ? vin[cl][i] * scl[i] : vin[cl][i];
+  };
+  auto commit_raw = [&](float* rb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int cl = 0; cl < KC; ++cl) commit_raw_cl(cl, rb);
   };
   // ---- weights: the packed chunk is the LDS image; LDS-DMA copies it in 1-KB pieces (16 cout rows x 4 position
   // quads), six per wave.  Lane l of a piece lands in 16-byte slot l, so the source quad is XOR-swizzled with the
@@ -161,25 +164,24 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
 #pragma unroll
   for (int p4 = 0; p4 < 4; ++p4) b_lo[p4] = (kq * 16 + j) * 16 + ((p4 ^ ((j >> 2) & 3)) * 4);
 
-  fetch_raw(0, vinA);
+  fetch_raw(0);
   dma_u(0, u_s);
-  commit_raw(0, raw_s, vinA);
-  if (KC < a.Cin) fetch_raw(KC, vinA);
-  if (2 * KC < a.Cin) fetch_raw(2 * KC, vinB);
-  // one chunk: `vin` holds the raw brick of chunk c0+KC on entry and that of chunk c0+3*KC on exit
-  auto chunk = [&](int c0, int cur, float (&vin)[KC][NS]) __attribute__((always_inline)) {
-    // this chunk's weights (DMA, issued one chunk ago) have to be in LDS; the raw loads issued after them (KC*NS per
-    // thread, for chunk c0+2*KC) may stay in flight.  After the barrier every wave is done with the other pair of
-    // buffers and this chunk's raw brick is complete.
-    if (c0 + 2 * KC < a.Cin) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KC * NS) : "memory");
+  commit_raw(raw_s);
+  if (KC < a.Cin) fetch_raw(KC);
+  // one chunk: `vin` holds the raw brick of chunk c0+KC on entry and that of chunk c0+2*KC on exit
+  auto chunk = [&](int c0, int cur) __attribute__((always_inline)) {
+    // this chunk's weights (DMA, issued at the start of the previous chunk) have to be in LDS; the raw loads issued
+    // after them (KC*NS per thread, for chunk c0+KC) may stay in flight.  After the barrier every wave is done with
+    // the other pair of buffers and this chunk's raw brick is complete.
+    if (c0 + KC < a.Cin) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KC * NS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (c0 + KC < a.Cin) {
-      dma_u(c0 + KC, u_s + (cur ^ 1) * U_CHUNK);
-      commit_raw(c0 + KC, raw_s + (cur ^ 1) * RAW_FLOATS, vin);
-      if (c0 + 3 * KC < a.Cin) fetch_raw(c0 + 3 * KC, vin);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    // The staging of the next chunk (weight DMA, LDS commit of the raw registers, their refill two chunks ahead) is
+    // spread over the first MFMA groups below: between two MFMAs of a wave there are issue slots the matrix pipe does
+    // not need, and instructions placed there cost nothing, while a staging phase in front of the stream delays the
+    // first MFMA of every chunk.
+    const bool nxt = c0 + KC < a.Cin, refill = c0 + 2 * KC < a.Cin;
+    float* rbn = raw_s + (cur ^ 1) * RAW_FLOATS;
     const float* rb = raw_s + cur * RAW_FLOATS;
     const float* ub = u_s + cur * U_CHUNK;
     // MFMA stream: 12 groups (kd, position quad) of 8*MTW MFMAs.  The B fragments of group g+1, the raw patches of
@@ -227,6 +229,9 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
       const int kd = g >> 2, p4 = g & 3;
       if (g + 1 < 12) load_b(g + 1, (g + 1) & 1);
       if (p4 == 0 && kd < 2) load_patch(kd + 1);
+      if (g == 0 && nxt) dma_u(c0 + KC, u_s + (cur ^ 1) * U_CHUNK);
+      if (g >= 2 && g < 2 + KC && nxt) commit_raw_cl(g - 2, rbn);
+      if (g >= 2 + KC && g < 2 + 2 * KC && refill) fetch_raw_cl(c0 + 2 * KC, g - 2 - KC);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt)
@@ -240,23 +245,10 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  if constexpr (MTW == 1) {
-    for (int c0 = 0; c0 < a.Cin; c0 += 2 * KC) {
-      chunk(c0, 0, vinA);
-      if (c0 + KC < a.Cin) chunk(c0 + KC, 1, vinB);
-    }
-  } else {
-    // one call site: with 256 accumulators the register allocator spills thousands of registers around a second
-    // copy of the chunk body; the two raw register sets are swapped instead (KC*NS moves per chunk)
+  {
     int cur = 0;
 #pragma unroll 1
-    for (int c0 = 0; c0 < a.Cin; c0 += KC, cur ^= 1) {
-      chunk(c0, cur, vinA);
-#pragma unroll
-      for (int cl = 0; cl < KC; ++cl)
-#pragma unroll
-        for (int i = 0; i < NS; ++i) { const float tmp = vinA[cl][i]; vinA[cl][i] = vinB[cl][i]; vinB[cl][i] = tmp; }
-    }
+    for (int c0 = 0; c0 < a.Cin; c0 += KC, cur ^= 1) chunk(c0, cur);
   }
 
   // ---- epilogue: Y = At M A per tile, BN scale/bias, residual, activation.  M index m = tile (row m&1, column

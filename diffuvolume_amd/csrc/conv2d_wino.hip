@@ -1,0 +1,361 @@
+// K11w: the 3x3, dilation-1, stride-1 2-D convolutions (IGEV's ConvGRU / motion encoder / heads, KITTI15/core/update.py;
+// the residual blocks of the 2-D feature CNNs, SceneFlow/models/submodule.py:21-24,:192-215) in the Winograd
+// F(2x2, 3x3) form on v_mfma_f32_16x16x4_f32 -- the 2-D sibling of conv3d_wino.hip (same transforms in registers,
+// same XOR-swizzled LDS-DMA weight image, same staging spread into the MFMA groups), with the epilogue of
+// conv2d.hip: per-channel scale/bias, residual, activation (incl. sigmoid / tanh), `mul` and the GRU blend, and up
+// to four input tensors read as one virtual channel concatenation.
+//
+// Block = 4 waves = 16 x 16 outputs x 32 output channels; wave w owns rows 4w..4w+3: its MFMA tile is M = 16 Winograd
+// tiles (2 tile rows x 8 tile columns), N = 16 output channels, K = 4 input channels.  A chunk is 8 input channels =
+// two k-steps x 16 positions x 2 N-tiles = 64 MFMAs per wave; raw brick (18 x 18 per channel) and weights are
+// double-buffered in LDS (62 KB, two blocks per CU).
+
+#include <type_traits>
+
+#include "dv_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace w2 {
+constexpr int KC = 8, NKS = 2, NT = 2, TH = 16, TW = 16;
+constexpr int IY = TH + 2, IX = TW + 2;
+constexpr int PRAW = IY * IX;                 // 324 raw positions per channel
+constexpr int RX = 24;                        // row stride; with a channel stride = 32 mod 64 the 16 tiles x 2 channels of
+constexpr int RAWP = 480;                     // a 32-lane ds_read_b64 cover the 64 banks once (see conv3d_wino.hip)
+constexpr int RAW_FLOATS = KC * RAWP;
+constexpr int U_CHUNK = NKS * NT * 4 * 16 * 16;   // packed floats per (chunk, co block) = the LDS image, 16 KB
+constexpr int NS = (PRAW + 255) / 256;
+static_assert(RAWP >= IY * RX && RAWP % 64 == 32, "bank plan of the patch reads");
+static_assert((RAW_FLOATS + U_CHUNK) * 2 * 4 * 2 <= 160 * 1024, "two blocks per CU, both stages double-buffered");
+}  // namespace w2
+
+struct Wino2dArgs {
+  const float* src[4];    // sources of the virtual channel concatenation ([B,c_k,H,W] each)
+  int cend[4];            // cumulative channel count after each source (cend[3] == Cin)
+  const float* wpk;       // [Cin/8][Coutp/32][ks 2][nt 2][k 4][n 16][pos 16]
+  const float* ch_scale;
+  const float* ch_bias;
+  const float* residual;
+  const float* mul;
+  const float* blend_z;
+  const float* blend_h;
+  float* out;
+  int B, Cin, H, W, Cout;
+  int ntx, nty, nco;
+  int act, fast_ok;
+};
+
+__global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
+  using namespace w2;
+  __shared__ __attribute__((aligned(1024))) float smem[2 * U_CHUNK + 2 * RAW_FLOATS];
+  float* u_s = smem;
+  float* raw_s = smem + 2 * U_CHUNK;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, kq = lane >> 4;
+
+  unsigned t = dv_xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = t % a.ntx; t /= a.ntx;
+  const int ty = t % a.nty; t /= a.nty;
+  const int tc = t % a.nco;
+  const int b = t / a.nco;
+  const int x0 = tx * TW, y0 = ty * TH, co0 = tc * 32;
+
+  f32x4 acc[16][NT];
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[p][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const size_t plane = (size_t)a.H * a.W;
+  const int plane_bytes = (int)(plane * sizeof(float));      // < 2^31 (checked by the host)
+
+  // ---- raw staging plan (as conv3d_wino.hip): buffer loads, zero padding and channel tail from the range check ----
+  unsigned sob[NS];
+  int lro[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int r = tid + 256 * i;
+    const int yy = r / IX, xx = r - yy * IX;
+    const int y = y0 - 1 + yy, x = x0 - 1 + xx;
+    const bool ok = r < PRAW && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+    sob[i] = ok ? (unsigned)(y * a.W + x) * 4u : 0x80000000u;
+    lro[i] = r < PRAW ? yy * RX + xx : IX;                   // lanes past the brick write a column no patch reads
+  }
+  float vin[KC][NS];
+  auto fetch_raw_cl = [&](int c0, int cl) __attribute__((always_inline)) {
+    const int c = c0 + cl;
+    const bool cok = c < a.Cin;
+    // source tensor of channel c in the virtual concatenation (scalar selects)
+    const int k = (c >= a.cend[0]) + (c >= a.cend[1]) + (c >= a.cend[2]);
+    const int cs = k == 0 ? 0 : a.cend[k - 1], cw = a.cend[k] - cs;
+    const float* base = cok ? a.src[k] + ((size_t)b * cw + (c - cs)) * plane : a.src[0];
+    const uint64_t ba = reinterpret_cast<uint64_t>(base);
+    const uint64_t bu = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ba) |
+                        ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ba >> 32)) << 32);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(bu), 0,
+                                                      __builtin_amdgcn_readfirstlane(cok ? plane_bytes : 0), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+      vin[cl][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)sob[i], 0, 0));
+  };
+  auto commit_raw_cl = [&](int cl, float* rb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) rb[cl * RAWP + lro[i]] = vin[cl][i];
+  };
+  // weights by LDS-DMA, source quad XOR-swizzled with the row (conv3d_wino.hip); 16 pieces of 1 KB, four per wave
+  const int dma_lo = (lane >> 2) * 16 + (((lane & 3) ^ ((lane >> 4) & 3)) * 4);
+  auto dma_u = [&](int c0, float* ub) __attribute__((always_inline)) {
+    const float* src = a.wpk + ((size_t)(c0 / KC) * a.nco + tc) * U_CHUNK + dma_lo;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int piece = wave + 4 * q;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 256),
+                                       (__attribute__((address_space(3))) void*)(ub + piece * 256), 16, 0, 0);
+    }
+  };
+
+  // this lane's 4x4 patch: tile (row j&1, column j>>1) of the wave's four rows, channel ks*4 + kq;  B rows (kq, j)
+  const int patch_lo = kq * RAWP + (4 * wave + 2 * (j & 1)) * RX + 2 * (j >> 1);
+  int b_lo[4];
+#pragma unroll
+  for (int p4 = 0; p4 < 4; ++p4) b_lo[p4] = (kq * 16 + j) * 16 + ((p4 ^ ((j >> 2) & 3)) * 4);
+
+#pragma unroll
+  for (int cl = 0; cl < KC; ++cl) fetch_raw_cl(0, cl);
+  dma_u(0, u_s);
+#pragma unroll
+  for (int cl = 0; cl < KC; ++cl) commit_raw_cl(cl, raw_s);
+  if (KC < a.Cin) {
+#pragma unroll
+    for (int cl = 0; cl < KC; ++cl) fetch_raw_cl(KC, cl);
+  }
+  int cur = 0;
+#pragma unroll 1
+  for (int c0 = 0; c0 < a.Cin; c0 += KC, cur ^= 1) {
+    // this chunk's weights (DMA issued at the start of the previous chunk) are in LDS; the raw loads issued after
+    // them (KC*NS per thread) may stay in flight
+    if (c0 + KC < a.Cin) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KC * NS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const bool nxt = c0 + KC < a.Cin, refill = c0 + 2 * KC < a.Cin;
+    float* rbn = raw_s + (cur ^ 1) * RAW_FLOATS;
+    const float* rb = raw_s + cur * RAW_FLOATS + patch_lo;
+    const float* ub = u_s + cur * U_CHUNK;
+    f32x2 d[4][2];
+    f32x4 bq[2][NT];
+    f32x2 vp[2][4][2];
+    auto load_patch = [&](int ks) __attribute__((always_inline)) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        d[r][0] = *reinterpret_cast<const f32x2*>(rb + ks * 4 * RAWP + r * RX);
+        d[r][1] = *reinterpret_cast<const f32x2*>(rb + ks * 4 * RAWP + r * RX + 2);
+      }
+    };
+    auto load_b = [&](int g, int slot) __attribute__((always_inline)) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        bq[slot][n] = *reinterpret_cast<const f32x4*>(ub + ((g >> 2) * NT + n) * (4 * 256) + b_lo[g & 3]);
+    };
+    auto transform = [&](int slot) __attribute__((always_inline)) {   // V = Bt d B, packed fp32 (conv3d_wino.hip)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        f32x2 t0, t1;
+        if (r == 0) { t0 = d[0][0] - d[2][0]; t1 = d[0][1] - d[2][1]; }
+        if (r == 1) { t0 = d[1][0] + d[2][0]; t1 = d[1][1] + d[2][1]; }
+        if (r == 2) { t0 = d[2][0] - d[1][0]; t1 = d[2][1] - d[1][1]; }
+        if (r == 3) { t0 = d[1][0] - d[3][0]; t1 = d[1][1] - d[3][1]; }
+        asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(vp[slot][r][0]) : "v"(t0), "v"(t1));
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]"
+            : "=v"(vp[slot][r][1]) : "v"(t1), "v"(t0));
+      }
+    };
+    load_patch(0);
+    load_b(0, 0);
+    transform(0);
+#pragma unroll
+    for (int g = 0; g < 4 * NKS; ++g) {
+      const int ks = g >> 2, p4 = g & 3;
+      if (g + 1 < 4 * NKS) load_b(g + 1, (g + 1) & 1);
+      if (p4 == 0 && ks + 1 < NKS) load_patch(ks + 1);
+      // next chunk's staging in the shadow of the MFMAs: DMA, then 2 channels of LDS commit / refill per group
+      if (g == 0 && nxt) dma_u(c0 + KC, u_s + (cur ^ 1) * U_CHUNK);
+      if (g < 4 && nxt) { commit_raw_cl(2 * g, rbn); commit_raw_cl(2 * g + 1, rbn); }
+      if (g >= 4 && refill) { fetch_raw_cl(c0 + 2 * KC, 2 * (g - 4)); fetch_raw_cl(c0 + 2 * KC, 2 * (g - 4) + 1); }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc[p4 * 4 + e][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[ks & 1][p4][e >> 1][e & 1], bq[g & 1][n][e],
+                                                                    acc[p4 * 4 + e][n], 0, 0, 0);
+      if (p4 == 1 && ks + 1 < NKS) transform((ks + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue: Y = At M A per tile; a lane (cout j, tiles 4kq..4kq+3) holds 4 consecutive x of four rows ----
+  const int yb = y0 + 4 * wave, xb = x0 + 4 * kq;
+  if (yb >= a.H) return;
+  const bool fast = a.fast_ok && x0 + TW <= a.W && yb + 4 <= a.H;
+  const float slope = a.act == DV_ACT_RELU ? 0.f : (a.act == DV_ACT_LEAKY ? 0.01f : 1.f);
+  const bool gen = a.act == DV_ACT_MISH || a.act == DV_ACT_SIGMOID || a.act == DV_ACT_TANH;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int co = co0 + n * 16 + j;
+    if (co >= a.Cout) continue;
+    const float sc = a.ch_scale ? a.ch_scale[co] : 1.f;
+    const float bi = a.ch_bias ? a.ch_bias[co] : 0.f;
+    const size_t cbase = (((size_t)b * a.Cout + co) * a.H + yb) * a.W + xb;
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr) {
+      float yv[2][4];
+#pragma unroll
+      for (int tcx = 0; tcx < 2; ++tcx) {
+        const int i = tr + 2 * tcx;
+        float s0[4], s1[4];
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+          const float m0 = acc[px][n][i], m1 = acc[4 + px][n][i], m2 = acc[8 + px][n][i], m3 = acc[12 + px][n][i];
+          s0[px] = m0 + m1 + m2;
+          s1[px] = m1 - m2 - m3;
+        }
+        yv[0][2 * tcx] = s0[0] + s0[1] + s0[2];
+        yv[0][2 * tcx + 1] = s0[1] - s0[2] - s0[3];
+        yv[1][2 * tcx] = s1[0] + s1[1] + s1[2];
+        yv[1][2 * tcx + 1] = s1[1] - s1[2] - s1[3];
+      }
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int yr = 2 * tr + r;
+        const size_t o = cbase + (size_t)yr * a.W;
+        if (fast) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaf(yv[r][e], sc, bi);
+          if (a.residual) v += *reinterpret_cast<const f32x4*>(a.residual + o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gen ? dv_act(v[e], a.act) : fmaxf(v[e], v[e] * slope);
+          if (a.mul) v *= *reinterpret_cast<const f32x4*>(a.mul + o);
+          if (a.blend_z) {
+            const f32x4 z = *reinterpret_cast<const f32x4*>(a.blend_z + o);
+            const f32x4 h = *reinterpret_cast<const f32x4*>(a.blend_h + o);
+            v = h + z * (v - h);
+          }
+          *reinterpret_cast<f32x4*>(a.out + o) = v;
+        } else if (yb + yr < a.H) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (xb + e < a.W) {
+              float u = fmaf(yv[r][e], sc, bi);
+              if (a.residual) u += a.residual[o + e];
+              u = dv_act(u, a.act);
+              if (a.mul) u *= a.mul[o + e];
+              if (a.blend_z) u = a.blend_h[o + e] + a.blend_z[o + e] * (u - a.blend_h[o + e]);
+              a.out[o + e] = u;
+            }
+        }
+      }
+    }
+  }
+}
+
+// U = G g Gt per (cout, cin);  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+__global__ void pack_wino2d_weights_kernel(const float* __restrict__ w, float* __restrict__ wpk, int Cin, int Cout,
+                                           int nchunk, int nco) {
+  const size_t total = (size_t)nchunk * nco * 2 * 2 * 4 * 16;   // one thread per (chunk, cb, ks, nt, k, n)
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    size_t r = i;
+    const int n = (int)(r % 16); r /= 16;
+    const int k = (int)(r % 4); r /= 4;
+    const int nt = (int)(r % 2); r /= 2;
+    const int ks = (int)(r % 2); r /= 2;
+    const int cb = (int)(r % nco);
+    const int ch = (int)(r / nco);
+    const int co = cb * 32 + nt * 16 + n, ci = ch * 8 + ks * 4 + k;
+    float g[3][3];
+    for (int p = 0; p < 3; ++p)
+      for (int q = 0; q < 3; ++q) g[p][q] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * 9 + p * 3 + q] : 0.f;
+    float gg[4][3];
+    for (int q = 0; q < 3; ++q) {
+      gg[0][q] = g[0][q];
+      gg[1][q] = 0.5f * (g[0][q] + g[1][q] + g[2][q]);
+      gg[2][q] = 0.5f * (g[0][q] - g[1][q] + g[2][q]);
+      gg[3][q] = g[2][q];
+    }
+    float* dst = wpk + i * 16;
+    for (int p = 0; p < 4; ++p) {
+      dst[p * 4 + 0] = gg[p][0];
+      dst[p * 4 + 1] = 0.5f * (gg[p][0] + gg[p][1] + gg[p][2]);
+      dst[p * 4 + 2] = 0.5f * (gg[p][0] - gg[p][1] + gg[p][2]);
+      dst[p * 4 + 3] = gg[p][2];
+    }
+  }
+}
+
+inline int cdiv2(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace
+
+extern "C" size_t dv_conv2d_wino_packed_floats(int Cin, int Cout) {
+  if (Cin <= 0 || Cout <= 0) return 0;
+  return (size_t)cdiv2(Cin, 8) * cdiv2(Cout, 32) * w2::U_CHUNK;
+}
+
+extern "C" int dv_conv2d_wino_pack_weights_f32(const float* w, float* wpacked, int Cin, int Cout,
+                                               dv_stream_t stream) {
+  DV_REQUIRE_PTR(w);
+  DV_REQUIRE_PTR(wpacked);
+  DV_REQUIRE(Cin > 0 && Cout > 0, DV_ERR_SHAPE);
+  const int nchunk = cdiv2(Cin, 8), nco = cdiv2(Cout, 32);
+  const size_t total = (size_t)nchunk * nco * 2 * 2 * 4 * 16;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_wino2d_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wpacked, Cin,
+                     Cout, nchunk, nco);
+  return dv_launch_status();
+}
+
+extern "C" int dv_conv2d_wino_cat_f32(const float* const* inputs, const int* channels, int n_inputs,
+                                      const float* wpacked, const float* ch_scale, const float* ch_bias,
+                                      const float* residual, const float* mul, const float* blend_z,
+                                      const float* blend_h, float* out, int B, int H, int W, int Cout, int act,
+                                      dv_stream_t stream) {
+  DV_REQUIRE_PTR(inputs);
+  DV_REQUIRE_PTR(channels);
+  DV_REQUIRE_PTR(wpacked);
+  DV_REQUIRE_PTR(out);
+  DV_REQUIRE(n_inputs >= 1 && n_inputs <= 4, DV_ERR_UNSUPPORTED);
+  DV_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0, DV_ERR_SHAPE);
+  DV_REQUIRE(act >= DV_ACT_NONE && act <= DV_ACT_TANH, DV_ERR_UNSUPPORTED);
+  DV_REQUIRE((blend_z == nullptr) == (blend_h == nullptr), DV_ERR_NULL);
+  DV_REQUIRE(dv_aligned16(wpacked), DV_ERR_ALIGN);
+  DV_REQUIRE((size_t)H * W * sizeof(float) <= 0x7fffffffull, DV_ERR_SHAPE);   // 31-bit byte offsets in a channel
+  Wino2dArgs a;
+  int cin = 0;
+  for (int i = 0; i < 4; ++i) {
+    if (i < n_inputs) {
+      DV_REQUIRE_PTR(inputs[i]);
+      DV_REQUIRE(channels[i] > 0, DV_ERR_SHAPE);
+      cin += channels[i];
+      a.src[i] = inputs[i];
+    } else {
+      a.src[i] = inputs[0];
+    }
+    a.cend[i] = cin;
+  }
+  a.wpk = wpacked; a.ch_scale = ch_scale; a.ch_bias = ch_bias; a.residual = residual; a.mul = mul;
+  a.blend_z = blend_z; a.blend_h = blend_h; a.out = out;
+  a.B = B; a.Cin = cin; a.H = H; a.W = W; a.Cout = Cout; a.act = act;
+  a.fast_ok = (W % 4 == 0) && dv_aligned16(out) && (!residual || dv_aligned16(residual)) &&
+              (!mul || dv_aligned16(mul)) && (!blend_z || (dv_aligned16(blend_z) && dv_aligned16(blend_h)));
+  a.ntx = cdiv2(W, w2::TW); a.nty = cdiv2(H, w2::TH); a.nco = cdiv2(Cout, 32);
+  const long long blocks = (long long)B * a.nco * a.nty * a.ntx;
+  if (blocks <= 0 || blocks > 0x7fffffffLL) return DV_ERR_SHAPE;
+  hipLaunchKernelGGL(conv2d_wino_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return dv_launch_status();
+}

@@ -324,7 +324,17 @@ class Conv2dPlan:
         with torch.cuda.device(w.device):
             _lib.check(lib.dv_conv2d_pack_weights_f32(w.data_ptr(), self.wpacked.data_ptr(), self.cin, self.cout, k,
                                                       self.dilation, _lib.stream_ptr()), "conv2d weight packing")
+            # 3x3, dilation 1, stride 1: also the Winograd F(2x2,3x3) image (csrc/conv2d_wino.hip), used when the
+            # launch has enough 16x16x32 blocks to fill the chip (small images stay on the direct kernel's small tiles)
+            self.wino_packed = None
+            if k == 3 and self.dilation == 1 and stride == 1 and default_conv_precision() == "f32":
+                self.wino_packed = torch.empty(lib.dv_conv2d_wino_packed_floats(self.cin, self.cout), dtype=torch.float32,
+                                               device=w.device)
+                _lib.check(lib.dv_conv2d_wino_pack_weights_f32(w.data_ptr(), self.wino_packed.data_ptr(), self.cin,
+                                                               self.cout, _lib.stream_ptr()), "conv2d wino weight packing")
         self.scale, self.shift = _fold_bn(bn, bias, self.cout, w.device, eps)
+
+    WINO_MIN_BLOCKS = 128
 
     def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, mul: Optional[torch.Tensor] = None,
                  blend: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
@@ -376,6 +386,22 @@ class Conv2dPlan:
         bz, bh = (None, None) if blend is None else (same(blend[0], "blend z"), same(blend[1], "blend h"))
         extra = sum(t is not None for t in (residual, mul, bz, bh))
         lib = _lib.load()
+        if self.wino_packed is not None and \
+                b * (-(-h // 16)) * (-(-w // 16)) * (-(-self.cout // 32)) >= self.WINO_MIN_BLOCKS:
+            import ctypes
+            srcs = parts if parts is not None else [x]
+            ptrs = (ctypes.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
+            chans = (ctypes.c_int * len(srcs))(*[t.shape[1] for t in srcs])
+            with torch.cuda.device(x.device):
+                nb = 4.0 * (sum(t.numel() for t in srcs) + out.numel() * (1 + extra))
+                timed(f"conv2d_k3d1_co{self.cout}", 2.0 * out.numel() * cin * 9, nb,
+                      lambda: _lib.check(lib.dv_conv2d_wino_cat_f32(ptrs, chans, len(srcs), self.wino_packed.data_ptr(),
+                                                                    _lib.ptr(self.scale), _lib.ptr(self.shift),
+                                                                    _lib.ptr(residual), _lib.ptr(mul), _lib.ptr(bz),
+                                                                    _lib.ptr(bh), out.data_ptr(), b, h, w, self.cout,
+                                                                    self.act, _lib.stream_ptr()),
+                                         "dv_conv2d_wino_cat_f32"))
+            return out
         if parts is not None:
             import ctypes
             ptrs = (ctypes.c_void_p * len(parts))(*[t.data_ptr() for t in parts])

@@ -168,6 +168,18 @@ int dv_conv2d_s2_f32(const float* in, const float* wpacked, const float* ch_scal
                      const float* residual, float* out, int B, int Cin, int H, int W, int Cout, int k, int act,
                      dv_stream_t stream);
 
+/* The 3x3, dilation-1, stride-1 case of dv_conv2d_cat_f32 in the Winograd F(2x2,3x3) form (csrc/conv2d_wino.hip): 2.25x
+ * fewer multiplies on the same fp32 MFMA instruction, same epilogue (scale/bias, residual, activation, `mul`, GRU
+ * blend) and the same virtual channel concatenation of up to four inputs; results equal dv_conv2d_cat_f32 up to fp32
+ * rounding.  `wpacked` from dv_conv2d_wino_pack_weights_f32 (its own layout). */
+size_t dv_conv2d_wino_packed_floats(int Cin, int Cout);
+int dv_conv2d_wino_pack_weights_f32(const float* w /*[Cout,Cin,3,3]*/, float* wpacked, int Cin, int Cout,
+                                    dv_stream_t stream);
+int dv_conv2d_wino_cat_f32(const float* const* inputs, const int* channels, int n_inputs, const float* wpacked,
+                           const float* ch_scale, const float* ch_bias, const float* residual, const float* mul,
+                           const float* blend_z, const float* blend_h, float* out, int B, int H, int W, int Cout,
+                           int act, dv_stream_t stream);
+
 /* Input assembly of that refinement (KITTI12/models/pwcnet_ddim.py:486-502), fused:
  *   frw = warp(right, disp)  (models/submodule.py:137-176, incl. its align_corners mismatch and >= 0.999 mask),
  *   cv  = build_corrleation_volume(left, frw, maxshift, 1)  (:121-135, incl. its negative-shift slicing),

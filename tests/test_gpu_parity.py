@@ -733,3 +733,59 @@ def test_ddim_sample_other_step_counts(acv_state_dict, steps):
     for i in range(1, steps + 1):
         assert float(e_h[i].median()) < 5e-4, (i, float(e_h[i].median()))
     assert float((fh.cpu().double() - f64).abs().median()) < 5e-4
+
+
+# ---------------------------------------------------------------- 2-D Winograd kernel (csrc/conv2d_wino.hip)
+@pytest.mark.parametrize("cfg", [((8,), 32, 16, 16, S.ACT_NONE), ((5, 7), 20, 9, 21, S.ACT_TANH),
+                                 ((32, 16, 8, 8), 48, 24, 40, S.ACT_SIGMOID), ((3,), 40, 5, 3, S.ACT_RELU),
+                                 ((33,), 33, 17, 50, S.ACT_MISH), ((16,), 1, 20, 36, S.ACT_NONE)])
+def test_conv2d_winograd(cfg, monkeypatch):
+    """The 2-D Winograd kernel forced onto shapes with partial tiles (odd H / W, rows that are not 16-byte aligned,
+    channel tails on both sides, 1..4 concatenated sources), with bias, residual, `mul` and the GRU blend, against
+    torch's fp64 convolution and against the direct 2-D kernel."""
+    cins, cout, h, w_, act = cfg
+    monkeypatch.setattr(S.Conv2dPlan, "WINO_MIN_BLOCKS", 0)
+    g = _gen(41, str(cfg))
+    b = 2
+    xs = [torch.randn(b, c, h, w_, generator=g) for c in cins]
+    cin = sum(cins)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    res, m = torch.randn(b, cout, h, w_, generator=g), torch.randn(b, cout, h, w_, generator=g)
+    z, hh = torch.rand(b, cout, h, w_, generator=g), torch.randn(b, cout, h, w_, generator=g)
+    y = torch.nn.functional.conv2d(torch.cat(xs, 1).double(), w.double(), bias.double(), 1, 1) + res.double()
+    y = {S.ACT_NONE: lambda t: t, S.ACT_RELU: torch.relu, S.ACT_TANH: torch.tanh, S.ACT_SIGMOID: torch.sigmoid,
+         S.ACT_MISH: lambda t: t * torch.tanh(torch.nn.functional.softplus(t))}[act](y)
+    ref = hh.double() + z.double() * (y * m.double() - hh.double())
+    plan = S.Conv2dPlan(dev(w), None, act=act, bias=dev(bias))
+    assert plan.wino_packed is not None
+    out = plan([dev(t) for t in xs], residual=dev(res), mul=dev(m), blend=(dev(z), dev(hh)))
+    torch.testing.assert_close(out.cpu().double(), ref, atol=2e-5, rtol=1e-5)
+    plan.wino_packed = None                       # the same plan on the direct kernel
+    direct = plan([dev(t) for t in xs], residual=dev(res), mul=dev(m), blend=(dev(z), dev(hh)))
+    torch.testing.assert_close(out, direct, atol=2e-5, rtol=1e-5)
+
+
+def test_conv2d_winograd_c_abi():
+    from diffuvolume_amd import _lib
+    import ctypes
+    lib = _lib.load()
+    g = _gen(42, "abi2d")
+    x, w = torch.randn(1, 12, 18, 36, generator=g), torch.randn(24, 12, 3, 3, generator=g) * 0.1
+    xd, wd = dev(x), dev(w)
+    n = lib.dv_conv2d_wino_packed_floats(12, 24)
+    assert n == 2 * 1 * 4096
+    wp, out = torch.empty(n, device=DEV), torch.empty(1, 24, 18, 36, device=DEV)
+    assert lib.dv_conv2d_wino_pack_weights_f32(wd.data_ptr(), wp.data_ptr(), 12, 24, _lib.stream_ptr()) == 0
+    ptrs, chans = (ctypes.c_void_p * 1)(xd.data_ptr()), (ctypes.c_int * 1)(12)
+    rc = lib.dv_conv2d_wino_cat_f32(ptrs, chans, 1, wp.data_ptr(), None, None, None, None, None, None, out.data_ptr(),
+                                    1, 18, 36, 24, S.ACT_NONE, _lib.stream_ptr())
+    assert rc == 0
+    assert rel_err(out, torch.nn.functional.conv2d(x.double(), w.double(), None, 1, 1).float()) < 1e-5
+    # refused: blend_z without blend_h, zero inputs, null output
+    assert lib.dv_conv2d_wino_cat_f32(ptrs, chans, 1, wp.data_ptr(), None, None, None, None, out.data_ptr(), None,
+                                      out.data_ptr(), 1, 18, 36, 24, 0, _lib.stream_ptr()) != 0
+    assert lib.dv_conv2d_wino_cat_f32(ptrs, chans, 0, wp.data_ptr(), None, None, None, None, None, None, out.data_ptr(),
+                                      1, 18, 36, 24, 0, _lib.stream_ptr()) != 0
+    assert lib.dv_conv2d_wino_cat_f32(ptrs, chans, 1, wp.data_ptr(), None, None, None, None, None, None, None,
+                                      1, 18, 36, 24, 0, _lib.stream_ptr()) != 0

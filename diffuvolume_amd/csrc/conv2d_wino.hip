@@ -48,11 +48,16 @@ struct Wino2dArgs {
   int act, fast_ok;
 };
 
+// DEEP: the low-occupancy variant for launches that do not fill the chip (IGEV's 1/8 and 1/16 scales at batch 1):
+// with one block or less per CU nothing hides a chunk's memory latency, so the weight DMA runs two chunks ahead
+// (ring of three LDS images) and the raw loads three (two register sets).
+template <bool DEEP>
 __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
   using namespace w2;
-  __shared__ __attribute__((aligned(1024))) float smem[2 * U_CHUNK + 2 * RAW_FLOATS];
+  constexpr int NU = DEEP ? 3 : 2;
+  __shared__ __attribute__((aligned(1024))) float smem[NU * U_CHUNK + 2 * RAW_FLOATS];
   float* u_s = smem;
-  float* raw_s = smem + 2 * U_CHUNK;
+  float* raw_s = smem + NU * U_CHUNK;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -74,6 +79,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
 
   const size_t plane = (size_t)a.H * a.W;
   const int plane_bytes = (int)(plane * sizeof(float));      // < 2^31 (checked by the host)
+  const int n_in = a.Cin;
 
   // ---- raw staging plan (as conv3d_wino.hip): buffer loads, zero padding and channel tail from the range check ----
   unsigned sob[NS];
@@ -87,10 +93,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
     sob[i] = ok ? (unsigned)(y * a.W + x) * 4u : 0x80000000u;
     lro[i] = r < PRAW ? yy * RX + xx : IX;                   // lanes past the brick write a column no patch reads
   }
-  float vin[KC][NS];
-  auto fetch_raw_cl = [&](int c0, int cl) __attribute__((always_inline)) {
+  typedef float RawSet[KC][NS];
+  RawSet vinA, vinB;      // (vinB is only used by the deep variant)
+  auto fetch_raw_cl = [&](int c0, int cl, RawSet& vin) __attribute__((always_inline)) {
     const int c = c0 + cl;
-    const bool cok = c < a.Cin;
+    const bool cok = c < n_in;
     // source tensor of channel c in the virtual concatenation (scalar selects)
     const int k = (c >= a.cend[0]) + (c >= a.cend[1]) + (c >= a.cend[2]);
     const int cs = k == 0 ? 0 : a.cend[k - 1], cw = a.cend[k] - cs;
@@ -104,7 +111,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
     for (int i = 0; i < NS; ++i)
       vin[cl][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)sob[i], 0, 0));
   };
-  auto commit_raw_cl = [&](int cl, float* rb) __attribute__((always_inline)) {
+  auto fetch_raw = [&](int c0, RawSet& vin) __attribute__((always_inline)) {
+#pragma unroll
+    for (int cl = 0; cl < KC; ++cl) fetch_raw_cl(c0, cl, vin);
+  };
+  auto commit_raw_cl = [&](int cl, float* rb, RawSet& vin) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NS; ++i) rb[cl * RAWP + lro[i]] = vin[cl][i];
   };
@@ -126,27 +137,41 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
 #pragma unroll
   for (int p4 = 0; p4 < 4; ++p4) b_lo[p4] = (kq * 16 + j) * 16 + ((p4 ^ ((j >> 2) & 3)) * 4);
 
-#pragma unroll
-  for (int cl = 0; cl < KC; ++cl) fetch_raw_cl(0, cl);
+  // ---- prologue.  Chunk k >= 1 travels in register set A (shallow) or set (k & 1 ? B : A) (deep) ----
+  fetch_raw(0, vinA);
   dma_u(0, u_s);
 #pragma unroll
-  for (int cl = 0; cl < KC; ++cl) commit_raw_cl(cl, raw_s);
-  if (KC < a.Cin) {
-#pragma unroll
-    for (int cl = 0; cl < KC; ++cl) fetch_raw_cl(KC, cl);
+  for (int cl = 0; cl < KC; ++cl) commit_raw_cl(cl, raw_s, vinA);
+  if (DEEP) {
+    if (KC < n_in) {
+      dma_u(KC, u_s + U_CHUNK);
+      fetch_raw(KC, vinB);
+    }
+    if (2 * KC < n_in) fetch_raw(2 * KC, vinA);
+  } else if (KC < n_in) {
+    fetch_raw(KC, vinA);
   }
-  int cur = 0;
-#pragma unroll 1
-  for (int c0 = 0; c0 < a.Cin; c0 += KC, cur ^= 1) {
-    // this chunk's weights (DMA issued at the start of the previous chunk) are in LDS; the raw loads issued after
-    // them (KC*NS per thread) may stay in flight
-    if (c0 + KC < a.Cin) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KC * NS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // one chunk.  `vin` holds the raw brick of chunk c0+KC on entry and is refilled for chunk c0+2*KC (deep: c0+3*KC);
+  // ub = LDS weight image of this chunk, unxt = target of the DMA issued in this chunk (chunk c0+KC, deep: c0+2*KC)
+  auto chunk = [&](int c0, int cur, const float* ub, float* unxt, RawSet& vin) __attribute__((always_inline)) {
+    // this chunk's weights (DMA) have to be in LDS; the loads issued after that DMA may stay in flight: the raw loads
+    // of the next chunk (shallow), or raw + DMA + raw of the next two (deep)
+    if (DEEP) {
+      if (c0 + 2 * KC < n_in) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KC * NS + 4) : "memory");
+      else if (c0 + KC < n_in) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KC * NS + 4) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (c0 + KC < n_in) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KC * NS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
-    const bool nxt = c0 + KC < a.Cin, refill = c0 + 2 * KC < a.Cin;
+    const bool nxt = c0 + KC < n_in;
+    const bool dma_ok = DEEP ? c0 + 2 * KC < n_in : nxt;
+    const bool refill = DEEP ? c0 + 3 * KC < n_in : c0 + 2 * KC < n_in;
+    const int c_dma = c0 + (DEEP ? 2 : 1) * KC, c_fetch = c0 + (DEEP ? 3 : 2) * KC;
     float* rbn = raw_s + (cur ^ 1) * RAW_FLOATS;
     const float* rb = raw_s + cur * RAW_FLOATS + patch_lo;
-    const float* ub = u_s + cur * U_CHUNK;
     f32x2 d[4][2];
     f32x4 bq[2][NT];
     f32x2 vp[2][4][2];
@@ -183,10 +208,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
       const int ks = g >> 2, p4 = g & 3;
       if (g + 1 < 4 * NKS) load_b(g + 1, (g + 1) & 1);
       if (p4 == 0 && ks + 1 < NKS) load_patch(ks + 1);
-      // next chunk's staging in the shadow of the MFMAs: DMA, then 2 channels of LDS commit / refill per group
-      if (g == 0 && nxt) dma_u(c0 + KC, u_s + (cur ^ 1) * U_CHUNK);
-      if (g < 4 && nxt) { commit_raw_cl(2 * g, rbn); commit_raw_cl(2 * g + 1, rbn); }
-      if (g >= 4 && refill) { fetch_raw_cl(c0 + 2 * KC, 2 * (g - 4)); fetch_raw_cl(c0 + 2 * KC, 2 * (g - 4) + 1); }
+      // staging in the shadow of the MFMAs: DMA, then 2 channels of LDS commit / refill per group
+      if (g == 0 && dma_ok) dma_u(c_dma, unxt);
+      if (g < 4 && nxt) { commit_raw_cl(2 * g, rbn, vin); commit_raw_cl(2 * g + 1, rbn, vin); }
+      if (g >= 4 && refill) { fetch_raw_cl(c_fetch, 2 * (g - 4), vin); fetch_raw_cl(c_fetch, 2 * (g - 4) + 1, vin); }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int n = 0; n < NT; ++n)
@@ -197,6 +222,22 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
       if (p4 == 1 && ks + 1 < NKS) transform((ks + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
     }
+  };
+  if (DEEP) {
+    // weight ring slot of chunk k = k % 3; raw LDS buffer k & 1; register set of chunk k+1 alternates B, A, B, ...
+    int iu = 0;
+#pragma unroll 1
+    for (int c0 = 0; c0 < n_in; c0 += 2 * KC) {
+      const int iu1 = iu == 2 ? 0 : iu + 1, iu2 = iu1 == 2 ? 0 : iu1 + 1;
+      chunk(c0, 0, u_s + iu * U_CHUNK, u_s + iu2 * U_CHUNK, vinB);
+      if (c0 + KC < n_in) chunk(c0 + KC, 1, u_s + iu1 * U_CHUNK, u_s + iu * U_CHUNK, vinA);
+      iu = iu2;
+    }
+  } else {
+    int cur = 0;
+#pragma unroll 1
+    for (int c0 = 0; c0 < n_in; c0 += KC, cur ^= 1)
+      chunk(c0, cur, u_s + cur * U_CHUNK, u_s + (cur ^ 1) * U_CHUNK, vinA);
   }
 
   // ---- epilogue: Y = At M A per tile; a lane (cout j, tiles 4kq..4kq+3) holds 4 consecutive x of four rows ----
@@ -356,6 +397,10 @@ extern "C" int dv_conv2d_wino_cat_f32(const float* const* inputs, const int* cha
   a.ntx = cdiv2(W, w2::TW); a.nty = cdiv2(H, w2::TH); a.nco = cdiv2(Cout, 32);
   const long long blocks = (long long)B * a.nco * a.nty * a.ntx;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return DV_ERR_SHAPE;
-  hipLaunchKernelGGL(conv2d_wino_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  // launches that leave most of the chip empty run the deep-prefetch variant
+  if (blocks < 512)
+    hipLaunchKernelGGL(conv2d_wino_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(conv2d_wino_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   return dv_launch_status();
 }

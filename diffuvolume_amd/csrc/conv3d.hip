@@ -125,7 +125,6 @@ __global__ __launch_bounds__(256, G::WPS) void conv3d_mfma_kernel(ConvArgs a) {
   constexpr int NQ = (G::KC / 2) * G::T * ROWQ;           // float4 per weight chunk
   constexpr int NWQ = (NQ + 255) / 256;
   unsigned sob[NS];                 // byte offset inside one channel volume (0 where the brick leaves the volume)
-  unsigned okmask = 0;              // bit i: position i is inside the volume
   float scl[HAS_SCALE ? NS : 1];    // the `volume * noise` prologue factor of that position
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
@@ -136,22 +135,29 @@ __global__ __launch_bounds__(256, G::WPS) void conv3d_mfma_kernel(ConvArgs a) {
     const bool ok = r < G::PRAW && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H &&
                     (unsigned)x < (unsigned)a.W;
     const unsigned sp = ok ? (unsigned)((z * a.H + y) * a.W + x) : 0u;
-    sob[i] = sp * 4u;
-    okmask |= ok ? (1u << i) : 0u;
+    sob[i] = ok ? sp * 4u : 0x80000000u;     // outside the volume: beyond the buffer's records -> the load returns 0
     if (HAS_SCALE) scl[i] = (ok && scb) ? scb[sp] : 1.f;
   }
+  const int vol_bytes = (int)(vol * sizeof(float));   // < 2^31 (checked by the host)
   float vin[G::KC][NS];
   f32x4 vw[NWQ];
   // global -> registers for one chunk of KC input channels (issued one chunk ahead of its use,
   // so HBM/L2 latency hides behind the previous chunk's MFMA stream).  Loads are unconditional (scalar channel
   // base + 32-bit lane offset); the zero padding is applied when the values are committed to LDS.
+  // Buffer loads, one descriptor per channel built on the scalar unit: the lane address is a 32-bit offset and both
+  // the zero padding and the channel tail (zero records) come out of the hardware range check.
   auto fetch = [&](int c0) {
 #pragma unroll
     for (int cl = 0; cl < G::KC; ++cl) {
-      const int ch = (c0 + cl) < a.Cin ? c0 + cl : 0;
-      const char* src = reinterpret_cast<const char*>(inb + (size_t)ch * vol);
+      const bool cok = (c0 + cl) < a.Cin;
+      const uint64_t ba = reinterpret_cast<uint64_t>(inb + (size_t)(cok ? c0 + cl : 0) * vol);
+      const uint64_t bu = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ba) |
+                          ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ba >> 32)) << 32);
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(bu), 0,
+                                                        __builtin_amdgcn_readfirstlane(cok ? vol_bytes : 0), 0x00020000);
 #pragma unroll
-      for (int i = 0; i < NS; ++i) vin[cl][i] = *reinterpret_cast<const float*>(src + sob[i]);
+      for (int i = 0; i < NS; ++i)
+        vin[cl][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)sob[i], 0, 0));
     }
     const float* wsrc = a.wpk + ((size_t)(c0 >> 1) * G::T * a.Coutp + co0) * 2;
 #pragma unroll
@@ -164,12 +170,10 @@ __global__ __launch_bounds__(256, G::WPS) void conv3d_mfma_kernel(ConvArgs a) {
   auto commit = [&](int c0) {  // registers -> LDS
 #pragma unroll
     for (int cl = 0; cl < G::KC; ++cl) {
-      const bool cok = (c0 + cl) < a.Cin;
 #pragma unroll
       for (int i = 0; i < NS; ++i) {
         const int r = tid + 256 * i;
-        const float v = (cok && ((okmask >> i) & 1u)) ? vin[cl][i] : 0.f;
-        if (r < G::PRAW) in_s[cl * G::P + r] = HAS_SCALE ? v * scl[i] : v;
+        if (r < G::PRAW) in_s[cl * G::P + r] = HAS_SCALE ? vin[cl][i] * scl[i] : vin[cl][i];
       }
     }
 #pragma unroll
@@ -535,7 +539,7 @@ extern "C" int dv_conv3d_f32(const float* in, const float* wpacked, const float*
   DV_REQUIRE(k == 1 || k == 3, DV_ERR_UNSUPPORTED);
   DV_REQUIRE(stride == 1 || stride == 2, DV_ERR_UNSUPPORTED);
   DV_REQUIRE(!(k == 1 && stride != 1), DV_ERR_UNSUPPORTED);
-  DV_REQUIRE((size_t)D * H * W * sizeof(float) <= 0xffffffffull, DV_ERR_SHAPE);    // 32-bit byte offsets inside a channel
+  DV_REQUIRE((size_t)D * H * W * sizeof(float) <= 0x7fffffffull, DV_ERR_SHAPE);    // 31-bit byte offsets inside a channel
   DV_REQUIRE(!(Cout == 1 && k == 3 && stride != 1), DV_ERR_UNSUPPORTED);   // the single-channel head is packed for its own stride-1 kernel
   DV_REQUIRE(act >= DV_ACT_NONE && act <= DV_ACT_LEAKY, DV_ERR_UNSUPPORTED);
   DV_REQUIRE(dv_aligned16(wpacked), DV_ERR_ALIGN);

@@ -110,8 +110,7 @@ __global__ __launch_bounds__(256, G::WPS) void conv2d_mfma_kernel(Conv2dArgs a) 
   // ---- staging plan: each thread owns NS positions of the staged rows (same for every channel) ----
   constexpr int NS = (G::RMAX * G::CMAX + 255) / 256;
   constexpr int NQ = G::W_FLOATS / 4, NWQ = (NQ + 255) / 256;
-  unsigned sob[NS];
-  unsigned okmask = 0;       // bit i: position i of this thread lies inside the image
+  unsigned sob[NS];          // byte offset in a channel plane, or 2^31 (beyond the buffer's records: the load returns 0)
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
     const int r = tid + 256 * i;
@@ -119,9 +118,9 @@ __global__ __launch_bounds__(256, G::WPS) void conv2d_mfma_kernel(Conv2dArgs a) 
     const int gy = G::BANDED ? y0 + (row / TH - 1) * d + row % TH : y0 * S - (KS / 2) * d + row;
     const int gx = x0 * S - (KS / 2) * d + col;
     const bool ok = r < R * C && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-    sob[i] = ok ? (unsigned)(gy * a.W + gx) * 4u : 0u;
-    okmask |= ok ? (1u << i) : 0u;
+    sob[i] = ok ? (unsigned)(gy * a.W + gx) * 4u : 0x80000000u;
   }
+  const int plane_bytes = (int)(plane * sizeof(float));      // < 2^31 (checked by the host)
   float vin[KC][NS];
   f32x4 vw[NWQ];
   const int nchunk = (a.Cin + KC - 1) / KC;
@@ -133,9 +132,17 @@ __global__ __launch_bounds__(256, G::WPS) void conv2d_mfma_kernel(Conv2dArgs a) 
       const int k = (cc >= a.cend[0]) + (cc >= a.cend[1]) + (cc >= a.cend[2]);
       const float* base = k == 0 ? sb[0] : (k == 1 ? sb[1] : (k == 2 ? sb[2] : sb[3]));
       const int c_in_src = cc - (k == 0 ? 0 : a.cend[k - 1]);
-      const char* src = reinterpret_cast<const char*>(base + (size_t)c_in_src * plane);
+      // buffer loads, one descriptor per channel built on the scalar unit: zero padding and the channel tail (zero
+      // records) come out of the hardware range check, the lane address is a 32-bit offset
+      const uint64_t ba = reinterpret_cast<uint64_t>(base + (size_t)c_in_src * plane);
+      const uint64_t bu = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ba) |
+                          ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ba >> 32)) << 32);
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(bu), 0,
+                                                        __builtin_amdgcn_readfirstlane(ch < a.Cin ? plane_bytes : 0),
+                                                        0x00020000);
 #pragma unroll
-      for (int i = 0; i < NS; ++i) vin[cl][i] = *reinterpret_cast<const float*>(src + sob[i]);
+      for (int i = 0; i < NS; ++i)
+        vin[cl][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)sob[i], 0, 0));
     }
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpk + ((size_t)c * a.nco + tc) * G::W_FLOATS);
 #pragma unroll
@@ -144,14 +151,13 @@ __global__ __launch_bounds__(256, G::WPS) void conv2d_mfma_kernel(Conv2dArgs a) 
       if (e < NQ) vw[q] = wsrc[e];
     }
   };
-  auto commit = [&](int c) {   // zero padding applied here: nothing may depend on a load in flight
+  auto commit = [&](int c) {
 #pragma unroll
     for (int cl = 0; cl < KC; ++cl) {
-      const bool cok = (c * KC + cl) < a.Cin;
 #pragma unroll
       for (int i = 0; i < NS; ++i) {
         const int r = tid + 256 * i;      // threads past the brick write the plane's spare slot
-        in_s[cl * P + (r < R * C ? r : P - 1)] = (cok && ((okmask >> i) & 1u)) ? vin[cl][i] : 0.f;
+        in_s[cl * P + (r < R * C ? r : P - 1)] = vin[cl][i];
       }
     }
 #pragma unroll
@@ -392,7 +398,7 @@ static int conv2d_run(const float* in, const float* const* more, const int* more
   DV_REQUIRE(act >= DV_ACT_NONE && act <= DV_ACT_TANH, DV_ERR_UNSUPPORTED);
   DV_REQUIRE((blend_z == nullptr) == (blend_h == nullptr), DV_ERR_NULL);
   DV_REQUIRE(dv_aligned16(wpacked), DV_ERR_ALIGN);
-  DV_REQUIRE((size_t)H * W * sizeof(float) <= 0xffffffffull, DV_ERR_SHAPE);
+  DV_REQUIRE((size_t)H * W * sizeof(float) <= 0x7fffffffull, DV_ERR_SHAPE);
   Conv2dArgs a;
   a.in = in;
   {   // Cin counts all sources; the first one owns what the others do not

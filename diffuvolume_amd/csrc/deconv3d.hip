@@ -112,8 +112,7 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
   constexpr int NQ = G::W_FLOATS / 4;
   constexpr int NWQ = (NQ + 255) / 256;
   static_assert(kP > kPRAW, "need a pad slot per channel plane");
-  unsigned sob[NS];
-  bool sok[NS];
+  unsigned sob[NS];     // byte offset in a channel volume, or 2^31 (beyond the buffer's records: the load returns 0)
   int wslot[NS];        // LDS slot of that position; threads past the brick write the plane's pad slot
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
@@ -122,20 +121,27 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
     const int yy = r2 / kIX, xx = r2 - yy * kIX;
     const int z = z0 - LO + zz, y = y0 - LO + yy, x = x0 - LO + xx;
     const bool ok = r < kPRAW && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-    sob[i] = ok ? (unsigned)((z * a.H + y) * a.W + x) * 4u : 0u;
-    sok[i] = ok;
+    sob[i] = ok ? (unsigned)((z * a.H + y) * a.W + x) * 4u : 0x80000000u;
     wslot[i] = r < kPRAW ? r : kP - 1;
   }
+  const int vol_bytes = (int)(vol * sizeof(float));   // < 2^31 (checked by the host)
   float vin[kKC][NS];
   f32x4 vw[NWQ];
   const int nchunk = (a.Cin + kKC - 1) / kKC;
   auto fetch = [&](int c) {
 #pragma unroll
     for (int cl = 0; cl < kKC; ++cl) {
-      const int ch = c * kKC + cl;
-      const char* src = reinterpret_cast<const char*>(inb + (size_t)(ch < a.Cin ? ch : 0) * vol);
+      // buffer loads, one descriptor per channel built on the scalar unit: zero padding and the channel tail (zero
+      // records) come out of the hardware range check, the lane address is a 32-bit offset
+      const bool cok = (c * kKC + cl) < a.Cin;
+      const uint64_t ba = reinterpret_cast<uint64_t>(inb + (size_t)(cok ? c * kKC + cl : 0) * vol);
+      const uint64_t bu = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ba) |
+                          ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ba >> 32)) << 32);
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(bu), 0,
+                                                        __builtin_amdgcn_readfirstlane(cok ? vol_bytes : 0), 0x00020000);
 #pragma unroll
-      for (int i = 0; i < NS; ++i) vin[cl][i] = *reinterpret_cast<const float*>(src + sob[i]);
+      for (int i = 0; i < NS; ++i)
+        vin[cl][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)sob[i], 0, 0));
     }
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpk + ((size_t)c * a.nco + tc) * G::W_FLOATS);
 #pragma unroll
@@ -144,13 +150,11 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
       if (e < NQ) vw[q] = wsrc[e];
     }
   };
-  auto commit = [&](int c) {   // zero padding is applied here, not at the load: nothing may depend on a load in flight
+  auto commit = [&](int c) {
 #pragma unroll
-    for (int cl = 0; cl < kKC; ++cl) {
-      const bool cok = (c * kKC + cl) < a.Cin;
+    for (int cl = 0; cl < kKC; ++cl)
 #pragma unroll
-      for (int i = 0; i < NS; ++i) in_s[cl * kP + wslot[i]] = (cok && sok[i]) ? vin[cl][i] : 0.f;
-    }
+      for (int i = 0; i < NS; ++i) in_s[cl * kP + wslot[i]] = vin[cl][i];
 #pragma unroll
     for (int q = 0; q < NWQ; ++q) {
       const int e = tid + 256 * q;
@@ -475,7 +479,7 @@ int run_any(const float* in, const float* wpacked, const float* ch_scale, const 
   a.nco = a.Coutp / kCOUT;
   a.act = act;
   a.vec_store = (W % 4 == 0) && dv_aligned16(out) && (!residual || dv_aligned16(residual));   // generic path's 32-byte stores
-  if ((size_t)D * H * W * sizeof(float) > 0xffffffffull) return DV_ERR_SHAPE;   // 32-bit in-channel byte offsets
+  if ((size_t)D * H * W * sizeof(float) > 0x7fffffffull) return DV_ERR_SHAPE;   // 31-bit in-channel byte offsets
   // fast epilogue: scalar row base + 32-bit per-lane byte offsets inside one batch item
   a.fast_ok = (W % 2 == 0) && dv_aligned16(out) && (!residual || dv_aligned16(residual)) &&
               (size_t)Cout * 8 * D * H * W * sizeof(float) <= 0xffffffffull;

@@ -106,8 +106,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16x3_kernel(Args a) {
   // staging plan: thread owns NS brick positions (all 8 channels of each)
   constexpr int NS = (NREAL + 255) / 256;
   constexpr int NWQ = (2 * W_H8 + 255) / 256;
-  unsigned sob[NS];                 // byte offset inside one channel volume (0 outside the volume)
-  unsigned okmask = 0;              // bit i: position i is inside the volume
+  unsigned sob[NS];                 // byte offset inside one channel volume (2^31 outside: the buffer load returns 0)
   float scl[HAS_SCALE ? NS : 1];    // activation scale x `volume * noise` factor
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
@@ -118,18 +117,25 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16x3_kernel(Args a) {
     const bool ok = r < NREAL && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H &&
                     (unsigned)x < (unsigned)a.W;
     const unsigned sp = ok ? (unsigned)((z * a.H + y) * a.W + x) : 0u;
-    sob[i] = sp * 4u;
-    okmask |= ok ? (1u << i) : 0u;
+    sob[i] = ok ? sp * 4u : 0x80000000u;
     if (HAS_SCALE) scl[i] = (ok && scb) ? scb[sp] * kActScale : kActScale;
   }
+  const int vol_bytes = (int)(vol * sizeof(float));   // < 2^31 (checked by the host)
   float vin[NS][KC];
   f32x4 vw[NWQ];
   auto fetch = [&](int c0) {
 #pragma unroll
     for (int cl = 0; cl < KC; ++cl) {
-      const char* src = reinterpret_cast<const char*>(inb + (size_t)((c0 + cl) < a.Cin ? c0 + cl : 0) * vol);
+      // buffer loads (one descriptor per channel, scalar): zero padding and channel tail from the range check
+      const bool cok = (c0 + cl) < a.Cin;
+      const uint64_t ba = reinterpret_cast<uint64_t>(inb + (size_t)(cok ? c0 + cl : 0) * vol);
+      const uint64_t bu = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ba) |
+                          ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ba >> 32)) << 32);
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(bu), 0,
+                                                        __builtin_amdgcn_readfirstlane(cok ? vol_bytes : 0), 0x00020000);
 #pragma unroll
-      for (int i = 0; i < NS; ++i) vin[i][cl] = *reinterpret_cast<const float*>(src + sob[i]);   // unconditional
+      for (int i = 0; i < NS; ++i)
+        vin[i][cl] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)sob[i], 0, 0));
     }
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpk) + (size_t)(c0 / KC) * 2 * KB * 4 * a.Coutp;
 #pragma unroll
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16x3_kernel(Args a) {
         // pair would be one fp16 ulp apart (seen once per ~10^4 elements before this was pinned)
         // (hipcc fused it even through __fmul_rn/__fsub_rn: v_fma_mixlo_f16 for lo, v_cvt_pk_f16_f32 of
         // the rounded product for hi -- the empty asm makes v opaque so the two cannot be re-derived.)
-        float v = ((c0 + cl) < a.Cin && ((okmask >> i) & 1u)) ? vin[i][cl] * (HAS_SCALE ? scl[i] : kActScale) : 0.f;
+        float v = vin[i][cl] * (HAS_SCALE ? scl[i] : kActScale);
         asm volatile("" : "+v"(v));
         vmax = fmaxf(vmax, fabsf(v));
         const _Float16 h = (_Float16)v;
@@ -294,6 +300,7 @@ extern "C" int dv_conv3d_f16x3_f32(const float* in, const void* wpacked, const f
   DV_REQUIRE_PTR(wpacked);
   DV_REQUIRE_PTR(out);
   DV_REQUIRE(B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0 && Cout > 0, DV_ERR_SHAPE);
+  DV_REQUIRE((size_t)D * H * W * sizeof(float) <= 0x7fffffffull, DV_ERR_SHAPE);   // 31-bit byte offsets in a channel
   DV_REQUIRE(act >= DV_ACT_NONE && act <= DV_ACT_LEAKY, DV_ERR_UNSUPPORTED);
   DV_REQUIRE(dv_aligned16(wpacked), DV_ERR_ALIGN);
   Args a;

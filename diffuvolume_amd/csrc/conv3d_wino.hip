@@ -164,6 +164,24 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
 #pragma unroll
   for (int p4 = 0; p4 < 4; ++p4) b_lo[p4] = (kq * 16 + j) * 16 + ((p4 ^ ((j >> 2) & 3)) * 4);
 
+  // LDS offsets (bytes from smem) of this chunk's patch / B rows and of the next chunk's raw brick: loop-carried and
+  // flipped between the two buffers with one add each per chunk (recomputing them from `cur` cost 28 vector
+  // instructions per chunk)
+  int po[MTW], bo[4], wo[NS];
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt) po[mt] = 4 * (2 * U_CHUNK + patch_lo[mt]);
+#pragma unroll
+  for (int p4 = 0; p4 < 4; ++p4) bo[p4] = 4 * b_lo[p4];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) wo[i] = 4 * (2 * U_CHUNK + RAW_FLOATS + lro[i]);
+  char* const smem_b = reinterpret_cast<char*>(smem);
+
+  auto commit_next_cl = [&](int cl) __attribute__((always_inline)) {   // into the other buffer, running offsets
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+      *reinterpret_cast<float*>(smem_b + wo[i] + 4 * cl * RAWP) = HAS_SCALE ? vin[cl][i] * scl[i] : vin[cl][i];
+  };
+
   fetch_raw(0);
   dma_u(0, u_s);
   commit_raw(raw_s);
@@ -181,9 +199,6 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
     // not need, and instructions placed there cost nothing, while a staging phase in front of the stream delays the
     // first MFMA of every chunk.
     const bool nxt = c0 + KC < a.Cin, refill = c0 + 2 * KC < a.Cin;
-    float* rbn = raw_s + (cur ^ 1) * RAW_FLOATS;
-    const float* rb = raw_s + cur * RAW_FLOATS;
-    const float* ub = u_s + cur * U_CHUNK;
     // MFMA stream: 12 groups (kd, position quad) of 8*MTW MFMAs.  The B fragments of group g+1, the raw patches of
     // the next plane(s) and their transform are issued in the shadow of group g (sched_barrier pins that order).
     f32x2 d[MTW][4][2];
@@ -194,14 +209,14 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
       for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          d[mt][r][0] = *reinterpret_cast<const f32x2*>(rb + patch_lo[mt] + (kd * IY + r) * RX);
-          d[mt][r][1] = *reinterpret_cast<const f32x2*>(rb + patch_lo[mt] + (kd * IY + r) * RX + 2);
+          d[mt][r][0] = *reinterpret_cast<const f32x2*>(smem_b + po[mt] + 4 * ((kd * IY + r) * RX));
+          d[mt][r][1] = *reinterpret_cast<const f32x2*>(smem_b + po[mt] + 4 * ((kd * IY + r) * RX + 2));
         }
     };
     auto load_b = [&](int g, int slot) __attribute__((always_inline)) {
 #pragma unroll
       for (int n = 0; n < NT; ++n)
-        bq[slot][n] = *reinterpret_cast<const f32x4*>(ub + ((g >> 2) * NT + n) * (KC * 256) + b_lo[g & 3]);
+        bq[slot][n] = *reinterpret_cast<const f32x4*>(smem_b + bo[g & 3] + 4 * (((g >> 2) * NT + n) * (KC * 256)));
     };
     // V = Bt d B on packed-fp32 adds: rows as register pairs (two columns at a time), then per row the column
     // combinations (t0-t2, t1+t2) and (t2-t1, t1-t3) as one v_pk_add_f32 each (op_sel picks the halves, neg_* the
@@ -212,10 +227,14 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           f32x2 t0, t1;
-          if (r == 0) { t0 = d[mt][0][0] - d[mt][2][0]; t1 = d[mt][0][1] - d[mt][2][1]; }
-          if (r == 1) { t0 = d[mt][1][0] + d[mt][2][0]; t1 = d[mt][1][1] + d[mt][2][1]; }
-          if (r == 2) { t0 = d[mt][2][0] - d[mt][1][0]; t1 = d[mt][2][1] - d[mt][1][1]; }
-          if (r == 3) { t0 = d[mt][1][0] - d[mt][3][0]; t1 = d[mt][1][1] - d[mt][3][1]; }
+          const int ra = r == 0 ? 0 : (r == 2 ? 2 : 1), rb2 = r == 0 ? 2 : (r == 1 ? 2 : (r == 2 ? 1 : 3));
+          if (r == 1) {
+            asm("v_pk_add_f32 %0, %1, %2" : "=v"(t0) : "v"(d[mt][ra][0]), "v"(d[mt][rb2][0]));
+            asm("v_pk_add_f32 %0, %1, %2" : "=v"(t1) : "v"(d[mt][ra][1]), "v"(d[mt][rb2][1]));
+          } else {
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t0) : "v"(d[mt][ra][0]), "v"(d[mt][rb2][0]));
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t1) : "v"(d[mt][ra][1]), "v"(d[mt][rb2][1]));
+          }
           asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(vp[mt][slot][r][0]) : "v"(t0), "v"(t1));
           asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]"
               : "=v"(vp[mt][slot][r][1]) : "v"(t1), "v"(t0));
@@ -230,7 +249,7 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
       if (g + 1 < 12) load_b(g + 1, (g + 1) & 1);
       if (p4 == 0 && kd < 2) load_patch(kd + 1);
       if (g == 0 && nxt) dma_u(c0 + KC, u_s + (cur ^ 1) * U_CHUNK);
-      if (g >= 2 && g < 2 + KC && nxt) commit_raw_cl(g - 2, rbn);
+      if (g >= 2 && g < 2 + KC && nxt) commit_next_cl(g - 2);
       if (g >= 2 + KC && g < 2 + 2 * KC && refill) fetch_raw_cl(c0 + 2 * KC, g - 2 - KC);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -244,6 +263,13 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
       if (p4 == 1 && kd < 2) transform((kd + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
     }
+    const int dr = cur ? -4 * RAW_FLOATS : 4 * RAW_FLOATS, du = cur ? -4 * U_CHUNK : 4 * U_CHUNK;   // scalar
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) po[mt] += dr;
+#pragma unroll
+    for (int p4 = 0; p4 < 4; ++p4) bo[p4] += du;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) wo[i] -= dr;
   };
   {
     int cur = 0;

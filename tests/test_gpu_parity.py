@@ -789,3 +789,24 @@ def test_conv2d_winograd_c_abi():
                                       1, 18, 36, 24, 0, _lib.stream_ptr()) != 0
     assert lib.dv_conv2d_wino_cat_f32(ptrs, chans, 1, wp.data_ptr(), None, None, None, None, None, None, None,
                                       1, 18, 36, 24, 0, _lib.stream_ptr()) != 0
+
+
+def test_precision_switch_selects_kernels(monkeypatch):
+    """'f32' (default) puts the 3x3x3 stride-1 layers and the 3x3 dilation-1 2-D layers on the Winograd kernels,
+    'f32_direct' keeps every layer on the direct implicit GEMMs; strided / dilated / 1x1 / single-channel layers are
+    direct either way."""
+    w3, w2 = torch.randn(32, 16, 3, 3, 3, device=DEV), torch.randn(32, 16, 3, 3, device=DEV)
+    S.set_default_conv_precision(None)
+    monkeypatch.delenv("DV_CONV_PRECISION", raising=False)
+    assert S.Conv3dPlan(w3).wino and S.Conv2dPlan(w2).wino_packed is not None
+    assert not S.Conv3dPlan(w3, stride=2).wino
+    assert not S.Conv3dPlan(torch.randn(1, 16, 3, 3, 3, device=DEV)).wino
+    assert not S.Conv3dPlan(torch.randn(32, 16, 1, 1, 1, device=DEV)).wino
+    assert S.Conv2dPlan(w2, dilation=2).wino_packed is None and S.Conv2dPlan(w2, stride=2).wino_packed is None
+    try:
+        S.set_default_conv_precision("f32_direct")
+        assert not S.Conv3dPlan(w3).wino and S.Conv2dPlan(w2).wino_packed is None
+    finally:
+        S.set_default_conv_precision(None)
+    monkeypatch.setenv("DV_CONV_PRECISION", "f32_direct")
+    assert not S.Conv3dPlan(w3).wino

@@ -116,15 +116,18 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
     lro[i] = r < PRAW ? (zz * IY + yy) * RX + xx : IX;      // lanes past the brick write a column no patch reads
     if (HAS_SCALE) scl[i] = (ok && scb) ? scb[sp] : 1.f;
   }
-  const int vol_bytes = (int)(vol * sizeof(float));          // < 2^31 (checked by the host)
+  const int vol_bytes = __builtin_amdgcn_readfirstlane((int)(vol * sizeof(float)));   // < 2^31 (checked by the host)
   float vin[KC][NS];                  // raw brick of the next chunk, refilled for the one after as soon as it is in LDS
-  auto fetch_raw_cl = [&](int c0, int cl) __attribute__((always_inline)) {
-    const bool cok = (c0 + cl) < a.Cin;
-    const uint64_t ba = reinterpret_cast<uint64_t>(inb + (size_t)(cok ? c0 + cl : 0) * vol);
-    const uint64_t bu = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ba) |
-                        ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ba >> 32)) << 32);
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(bu), 0,
-                                                      __builtin_amdgcn_readfirstlane(cok ? vol_bytes : 0), 0x00020000);
+  // channels are fetched strictly in order (chunk after chunk), so the descriptor base is a running scalar pointer
+  // (one 64-bit add per channel instead of a 64-bit multiply) and the tail test a running counter
+  uint64_t fb = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)reinterpret_cast<uint64_t>(inb)) |
+                ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(reinterpret_cast<uint64_t>(inb) >> 32)) << 32);
+  int fc = 0;
+  auto fetch_raw_cl = [&](int /*c0*/, int cl) __attribute__((always_inline)) {
+    const bool cok = fc < a.Cin;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(fb), 0, cok ? vol_bytes : 0, 0x00020000);
+    fb += (uint64_t)(unsigned)vol_bytes;
+    ++fc;
 #pragma unroll
     for (int i = 0; i < NS; ++i)
       vin[cl][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)sob[i], 0, 0));

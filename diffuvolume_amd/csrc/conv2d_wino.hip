@@ -191,10 +191,14 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         f32x2 t0, t1;
-        if (r == 0) { t0 = d[0][0] - d[2][0]; t1 = d[0][1] - d[2][1]; }
-        if (r == 1) { t0 = d[1][0] + d[2][0]; t1 = d[1][1] + d[2][1]; }
-        if (r == 2) { t0 = d[2][0] - d[1][0]; t1 = d[2][1] - d[1][1]; }
-        if (r == 3) { t0 = d[1][0] - d[3][0]; t1 = d[1][1] - d[3][1]; }
+        const int ra = r == 0 ? 0 : (r == 2 ? 2 : 1), rb2 = r == 0 ? 2 : (r == 1 ? 2 : (r == 2 ? 1 : 3));
+        if (r == 1) {
+          asm("v_pk_add_f32 %0, %1, %2" : "=v"(t0) : "v"(d[ra][0]), "v"(d[rb2][0]));
+          asm("v_pk_add_f32 %0, %1, %2" : "=v"(t1) : "v"(d[ra][1]), "v"(d[rb2][1]));
+        } else {
+          asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t0) : "v"(d[ra][0]), "v"(d[rb2][0]));
+          asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t1) : "v"(d[ra][1]), "v"(d[rb2][1]));
+        }
         asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(vp[slot][r][0]) : "v"(t0), "v"(t1));
         asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]"
             : "=v"(vp[slot][r][1]) : "v"(t1), "v"(t0));

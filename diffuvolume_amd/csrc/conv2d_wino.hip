@@ -216,7 +216,6 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
       if (g == 0 && dma_ok) dma_u(c_dma, unxt);
       if (g < 4 && nxt) { commit_raw_cl(2 * g, rbn, vin); commit_raw_cl(2 * g + 1, rbn, vin); }
       if (g >= 4 && refill) { fetch_raw_cl(c_fetch, 2 * (g - 4), vin); fetch_raw_cl(c_fetch, 2 * (g - 4) + 1, vin); }
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -224,7 +223,6 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
           acc[p4 * 4 + e][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[ks & 1][p4][e >> 1][e & 1], bq[g & 1][n][e],
                                                                     acc[p4 * 4 + e][n], 0, 0, 0);
       if (p4 == 1 && ks + 1 < NKS) transform((ks + 1) & 1);
-      __builtin_amdgcn_sched_barrier(0);
     }
   };
   if (DEEP) {

@@ -11,7 +11,10 @@ pairs per GPU, inputs already resident in HBM:
     + masked EPE/D1 sums (K9);  one all-reduce of the metric sums after the K steps (RCCL).
 Workload = BASELINE.json configs[1]: SceneFlow ACVNet+DiffuVolume, 960x540 frames cropped to
 960x512 as the reference's loader does (sceneflow_dataset.py:60-65), maxdisp 192, batch 8 per
-GPU, 5 DDIM steps, fp32.  N>1: one process per GPU (torchrun), weak scaling.
+GPU, 5 DDIM steps, fp32.  N>1: one process per GPU over RCCL, weak scaling -- either launched by
+torchrun (RANK / LOCAL_RANK / WORLD_SIZE in the environment) or, when those are absent, by this
+script itself: `python bench.py --gpus N` starts N workers (before anything touches the GPU), and
+fails if fewer than N devices are visible.  It never silently measures fewer GPUs than asked.
 
 Prints ONE JSON line (rank 0): the driver contract plus `roofline` (dominant kernel: the
 fp32-MFMA Winograd conv of the 32-channel layers, HIP-event timed inside the timed region) and `cpu_baseline`
@@ -39,6 +42,12 @@ ALGO_FLOP_PER_PAIR = 3.76e12
 
 DOMINANT_KERNEL = "conv3d_wino_kernel<false, 1>"
 WINO_MULT_REDUCTION = 2.25        # F(2x2,3x3) in-plane: 16 multiplies per 2x2 outputs and depth tap instead of 36
+# the next kernels by time: (KernelTimer tags, rocprofv3 kernel name, issued-flop divisor)
+SIDE_KERNELS = [
+    (("deconv3d_k3s2_redir",), "deconv3d_mfma_kernel<3, 8>", 1.0),
+    (("conv3d_k3s2_co64", "conv3d_k3s2_co128"), "conv3d_mfma_kernel<Geo<3, 2, 4, 2, 4, 2, 4, 2>, true>", 1.0),
+    (("conv3d_k3s1_co32_filter",), "conv3d_wino_kernel<true, 1>", WINO_MULT_REDUCTION),
+]
 
 
 def pmc_traffic(kernel):
@@ -68,27 +77,71 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the split-fp16 and end-to-end side measurements")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="plumbing check of the N-process launch on CPU (gloo): rendezvous + one all-reduce, no GPU work")
     return ap.parse_args()
+
+
+def launch_workers(a, argv):
+    """`python bench.py --gpus N` without a launcher: start N worker processes (one per GPU, the same command line)
+    with the torchrun environment and wait for them.  Runs BEFORE this process touches the GPU and never re-execs
+    itself; `torch.cuda.device_count()` does not initialise HIP."""
+    import socket
+    import subprocess
+    if not a.dry_run:
+        n_vis = torch.cuda.device_count()
+        if n_vis < a.gpus:
+            print(f"bench.py: --gpus {a.gpus} but only {n_vis} GPU(s) visible; refusing to measure fewer", file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", DV_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0:
+                rc = rc or (code if code > 0 else 1)
+                for q in alive:               # a dead rank would leave the others waiting in a collective
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def dry_run(a):
+    """Worker side of --dry-run: rendezvous over gloo, one all-reduce, rank 0 prints what it saw."""
+    import torch.distributed as dist
+    from diffuvolume_amd import distributed as D
+    rank, world, _ = D.init_from_env(backend="gloo")
+    seen = torch.ones(1, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(seen)
+        dist.barrier()
+    lo, hi = D.shard_range(a.batch * world, rank, world)
+    shard = torch.tensor([float(hi - lo)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(shard)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": int(seen.item()), "backend": "gloo",
+                          "global_batch": int(shard.item()), "launcher": "self" if os.environ.get("DV_BENCH_SELF_LAUNCHED") else "torchrun"}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
 
 
 def make_inputs(batch, h, w, seed, device):
     """Synthetic quarter-resolution features with a real correlation ridge."""
-    from diffuvolume_amd.synth import _gen
-    g = _gen(seed, f"bench{batch}x{h}x{w}")
-    shifts = (6, 24, 60)
-
-    def pair(c):
-        left = torch.randn(batch, c, h, w, generator=g)
-        right = torch.stack([torch.roll(left[i], -(shifts[i % 3] // 4), dims=-1) for i in range(batch)])
-        return left, right + 0.05 * torch.randn(batch, c, h, w, generator=g)
-
-    fl, fr = pair(320)
-    cl, cr = pair(32)
-    att = torch.randn(batch, 1, 48, h, w, generator=g) * 2
-    gt = torch.stack([shifts[i % 3] + torch.randn(4 * h, 4 * w, generator=g) for i in range(batch)]).clamp(0.5, 191)
-    used = (gt + 0.5 * torch.randn(batch, 4 * h, 4 * w, generator=g)).clamp(0, 191)
-    dq = torch.nn.functional.interpolate(used.unsqueeze(1), size=(h, w), mode="bilinear") / 4
-    host = dict(fl=fl, fr=fr, cl=cl, cr=cr, att=att, gt=gt, used=used, dq=dq)
+    from diffuvolume_amd.synth import synth_hot_inputs
+    host = synth_hot_inputs(batch, h, w, seed)
     return host, {k: v.to(device) for k, v in host.items()}
 
 
@@ -102,29 +155,49 @@ def hot_path(model, x, tape=None):
     return final, stack, gwc
 
 
-def cpu_baseline(sd, host, ddim_steps):
-    """The CPU oracle on a bounded sample: pair 0, both builders + ONE DDIM step at full size;
-    pairs/s extrapolated as 1 / (t_builders + S * t_step)."""
-    import torch.nn.functional as F
+def cpu_baseline(sd, host, ddim_steps, cof, seed=1):
+    """The CPU oracle on a bounded sample of the same workload: pair 0 at full size, both builders and the WHOLE
+    S-step DDIM loop (nothing extrapolated), noise from a NoiseTape so that the GPU can be compared on the same draws.
+    Returns (baseline dict, everything the parity leg needs)."""
     from oracle import acv_oracle as O
+    from oracle import loop_parity as LP
     one = {k: v[:1].clone() for k, v in host.items()}
-    orc = O.ACVDiffusionOracle(sd)
+    orc = O.ACVDiffusionOracle(sd, sampling_timesteps=ddim_steps, cof=cof)
     t0 = time.perf_counter()
     gwc = O.build_gwc_volume(one["fl"], one["fr"], 48, 40)
     vol = O.attention_concat_volume(one["att"], O.build_concat_volume(one["cl"], one["cr"], 48))
     x_T = orc.encode_x_T(one["dq"])
     t1 = time.perf_counter()
-    t = torch.full((1,), 999, dtype=torch.long)
-    _, _, disp, prob = orc.model_predictions(vol, x_T, t)
-    O.disparity_uncertainty(disp, prob)
+    final, stack, trace = LP.oracle_trajectory(orc, vol, one["used"], x_T, seed)
     t2 = time.perf_counter()
-    del gwc, prob
-    tb, ts = t1 - t0, t2 - t1
-    return {"value": 1.0 / (tb + ddim_steps * ts), "unit": "pairs/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"oracle/acv_oracle.py, 1 pair 960x512: builders {tb:.2f} s + 1 of {ddim_steps} DDIM steps "
-                      f"{ts:.2f} s, extrapolated to {ddim_steps} steps",
-            "builders_s": tb, "ddim_step_s": ts}, disp
+    del gwc
+    tb, tl = t1 - t0, t2 - t1
+    base = {"value": 1.0 / (tb + tl), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "extrapolated": False,
+            "sample": f"oracle/acv_oracle.py, 1 pair 960x512, the whole hot path: builders {tb:.2f} s + "
+                      f"{ddim_steps} DDIM steps {tl:.2f} s",
+            "builders_s": tb, "ddim_loop_s": tl}
+    return base, dict(one=one, x_T=x_T, final=final, stack=stack, trace=trace, seed=seed)
+
+
+def parity_vs_oracle(model, x, ref):
+    """All S steps of pair 0 against the oracle run of `cpu_baseline` (oracle/loop_parity.py): every step from the
+    oracle's state (teacher forced: the contract's bars apply), and the free run with the count of renewal
+    decisions that came out differently."""
+    from oracle import loop_parity as LP
+    import diffuvolume_amd as dv
+    one = {k: v[:1] for k, v in x.items()}
+    host = ref["one"]
+    with torch.no_grad():
+        vol_d = dv.build_concat_attention_volume(one["cl"], one["cr"], one["att"], 48)
+        tf = LP.teacher_forced(model, ref["trace"], vol_d, one["used"], host["used"], host["gt"])
+        fr = LP.free_run(model, ref["trace"], ref["stack"], ref["final"], vol_d, one["used"], ref["x_T"], host["gt"],
+                         ref["seed"])
+    keys = ("step", "mean_abs_px", "frac_gt_1e-3", "epe_delta", "flips_mask_zero")
+    return {"bars": {"px": LP.BAR_PX, "frac": LP.BAR_FRAC, "epe": LP.BAR_EPE},
+            "teacher_forced": [{k: s[k] for k in keys} for s in tf],
+            "teacher_forced_within_bars": all(s["frac_gt_1e-3"] <= LP.BAR_FRAC and s["epe_delta"] < LP.BAR_EPE for s in tf),
+            "free_run": [{k: s[k] for k in keys} for s in fr["steps"]], "free_run_final": fr["final"]}
 
 
 def extras(a, sd, x, mask, device):
@@ -188,10 +261,19 @@ def extras(a, sd, x, mask, device):
 
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: be the launcher (nothing has touched the GPU yet; children are started, never exec'd into)
+        raise SystemExit(launch_workers(a, sys.argv[1:]))
+    if a.dry_run:
+        if int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:
+            raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}")
+        raise SystemExit(dry_run(a))
     from diffuvolume_amd import distributed as D
     rank, world, local = D.init_from_env()
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: refusing to report a different GPU count")
     assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU visible"
     torch.cuda.set_device(D.device_index(local))
     device = torch.device("cuda", D.device_index(local))
@@ -239,6 +321,12 @@ def main():
 
     pairs = a.batch * world * a.steps
     value = pairs / dt
+    rccl_ranks = 1
+    if world > 1:                              # read the group size back through the collective itself
+        ones = torch.ones(1, device=device)
+        torch.distributed.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        assert rccl_ranks == a.gpus, (rccl_ranks, a.gpus)
     out = {
         "metric": "stereo pairs/sec, SceneFlow 960x540 (cropped 960x512) maxdisp=192, hot path",
         "value": value, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -248,7 +336,11 @@ def main():
                                f"{a.ddim_steps} DDIM steps + EPE), {a.width}x{a.height}, maxdisp=192, "
                                f"batch={a.batch}/GPU, random-init weights",
                    "global_batch": a.batch * world, "ddim_steps": a.ddim_steps, "parallelism": f"dp{world}"},
+        "rccl_ranks": rccl_ranks,
+        "launcher": "self" if os.environ.get("DV_BENCH_SELF_LAUNCHED") else ("torchrun" if world > 1 else "single"),
         "epe_px": epe["EPE"],
+        "epe_note": "random-init weights and synthetic pairs: the number only shows the metric path runs; dataset EPE "
+                    "(0.46 px, README) is unpinned -- no checkpoint or data ship with the reference",
         "hbm_roofline_frac_whole_path": value / world * ALGO_BYTES_PER_PAIR / (PEAK_HBM_GBS * 1e9),
         "mfma_f32_roofline_frac_whole_path": value / world * ALGO_FLOP_PER_PAIR / (PEAK_MFMA_F32_TFLOPS * 1e12),
     }
@@ -262,36 +354,53 @@ def main():
             flops = sum(v["flops"] for v in fam.values())
             ms = sum(v["total_ms"] for v in fam.values())
             launches = sum(v["launches"] for v in fam.values())
-            ach = flops / (ms * 1e-3) / 1e12
-            # `achieved` is the contract's figure: ALGORITHMIC flop (direct-convolution count, SURVEY 8d: 2*27*Cin*Cout
-            # per output voxel) per second.  The kernel is the Winograd F(2x2,3x3) form, which issues 2.25x fewer MFMA
-            # flops than that count, so `frac` can exceed 1; `mfma_issued` prices the matrix pipe with the flops
-            # actually issued.
-            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": pmc_traffic(DOMINANT_KERNEL),
+            algo = flops / (ms * 1e-3) / 1e12
+            issued = algo / WINO_MULT_REDUCTION
+            algo_bytes = sum(v["bytes"] for v in fam.values()) / launches
+            traffic = pmc_traffic(DOMINANT_KERNEL)
+            # `achieved` / `frac` price the matrix pipe with the flops the kernel ISSUES: the Winograd F(2x2,3x3) form
+            # executes 2.25x fewer multiplies than the direct-convolution (algorithmic, SURVEY 8d: 2*27*Cin*Cout per
+            # output voxel) count, which is reported beside it as `algorithmic_tflops`.
+            out["roofline"] = {"bound": "mfma", "achieved": issued, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                               "frac": issued / PEAK_MFMA_F32_TFLOPS, "traffic": traffic,
+                               "algorithmic_tflops": algo, "multiply_reduction": WINO_MULT_REDUCTION,
+                               "algorithmic_bytes_per_launch": algo_bytes,
+                               "traffic_over_algorithmic": None if traffic is None else traffic / algo_bytes,
                                "kernel": DOMINANT_KERNEL + " (all 3x3x3 stride-1 layers of dres0/dres1/hourglass/classif2 "
                                          "except the filter layer; Winograd F(2x2,3x3) in-plane, depth taps direct, "
                                          "v_mfma_f32_16x16x4_f32)",
                                "launches": launches, "avg_ms": ms / launches,
                                "algorithmic_gflop_per_launch": flops / launches / 1e9,
                                "by_layer": {k: {"launches": v["launches"], "avg_ms": v["avg_ms"],
-                                                "algorithmic_tflops": v["flops"] / v["total_ms"] / 1e9}
-                                            for k, v in sorted(fam.items())},
-                               "mfma_issued": {"tflops": ach / WINO_MULT_REDUCTION,
-                                               "frac": ach / WINO_MULT_REDUCTION / PEAK_MFMA_F32_TFLOPS,
-                                               "note": "algorithmic flop / 2.25 = multiplies the Winograd form executes"}}
+                                                "algorithmic_tflops": v["flops"] / v["total_ms"] / 1e9,
+                                                "issued_frac": v["flops"] / v["total_ms"] / 1e9 / WINO_MULT_REDUCTION
+                                                               / PEAK_MFMA_F32_TFLOPS}
+                                            for k, v in sorted(fam.items())}}
+        side = []
+        for tags, kname, div in SIDE_KERNELS:
+            sel = [ks[t] for t in tags if t in ks]
+            if not sel:
+                continue
+            fl, ms = sum(v["flops"] for v in sel), sum(v["total_ms"] for v in sel)
+            n = sum(v["launches"] for v in sel)
+            ab = sum(v["bytes"] for v in sel) / n
+            tr = pmc_traffic(kname)
+            side.append({"kernel": kname, "tags": list(tags), "bound": "mfma", "launches": n, "avg_ms": ms / n,
+                         "ms_per_step": ms / a.steps, "achieved": fl / ms / 1e9 / div, "unit": "TFLOP/s",
+                         "peak": PEAK_MFMA_F32_TFLOPS, "frac": fl / ms / 1e9 / div / PEAK_MFMA_F32_TFLOPS,
+                         "algorithmic_tflops": fl / ms / 1e9, "multiply_reduction": div,
+                         "algorithmic_bytes_per_launch": ab, "traffic": tr,
+                         "traffic_over_algorithmic": None if tr is None else tr / ab})
+        out["roofline_kernels"] = side
         out["kernels_ms_per_step"] = {k: round(v["total_ms"] / a.steps, 3) for k, v in sorted(ks.items())}
         out["kernels_tflops_or_gbs"] = {
             k: (round(v["flops"] / v["total_ms"] / 1e9, 2) if k.startswith(("conv", "deconv", "window"))
                 else round(v["bytes"] / v["total_ms"] / 1e6, 1)) for k, v in sorted(ks.items())}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        base, disp_cpu = cpu_baseline(sd, host, a.ddim_steps)
+        base, ref = cpu_baseline(sd, host, a.ddim_steps, model.ensemble_cof)
         out["cpu_baseline"] = base
-        with torch.no_grad():
-            one = {k: v[:1] for k, v in x.items()}
-            _, stack, _ = hot_path(model, one, NoiseTape(1))
-        d = (stack[1].cpu() - disp_cpu).abs()
-        out["parity_vs_oracle_step1"] = {"mean_abs_px": float(d.mean()), "frac_gt_1e-3": float((d > 1e-3).float().mean())}
+        out["parity_vs_oracle"] = parity_vs_oracle(model, x, ref)
+        del ref
     if rank == 0 and world == 1 and not a.no_extras:
         out["extras"] = extras(a, sd, x, mask, device)
     if rank == 0:

@@ -118,7 +118,8 @@ class FeatureExtraction(nn.Module):
         return super()._load_from_state_dict(*a, **k)
 
     def train(self, mode: bool = True):
-        self._plans = None
+        if mode != self.training:
+            self._plans = None
         return super().train(mode)
 
     def prepare(self):
@@ -253,6 +254,22 @@ class _Plans:
             self.alphas_cumprod = ac
             self.sqrt_recip = torch.sqrt(1.0 / ac)
             self.sqrt_recipm1 = torch.sqrt(1.0 / ac - 1)
+        self.loop_key = self.loop_steps = None          # per-step constants of the DDIM loop (ACVNet_DDIM._loop_plan)
+        self.weights_version = -1
+
+
+class _LoopStep:
+    """Everything one DDIM step needs that depends only on its timestep: the coefficient struct handed to
+    ``dv_ddim_step`` by value and the time-MLP shift (device resident; one row per batch entry on demand)."""
+
+    def __init__(self, time: int, time_next: int, coef: "_lib.DvDdimCoef", shift: torch.Tensor):
+        self.time, self.time_next, self.coef, self.shift = time, time_next, coef, shift
+        self._rows = {}
+
+    def shift_rows(self, b: int) -> torch.Tensor:
+        if b not in self._rows:
+            self._rows[b] = self.shift.reshape(1, -1).expand(b, -1).contiguous()
+        return self._rows[b]
 
 
 class ProbVolumeHandle:
@@ -280,24 +297,36 @@ def cosine_beta_schedule(timesteps: int, s: float = 0.008) -> torch.Tensor:
 
 class _HipPlanMixin(nn.Module):
     """Plan cache shared by the ACV wrappers: BatchNorm folding / weight repacking happens once per weight
-    set and is redone when parameters move or are reloaded."""
+    set and is redone when parameters move, are reloaded (through this module or any wrapper: ``nn.DataParallel(
+    model).load_state_dict`` only reaches ``_load_from_state_dict``) or the train/eval mode really changes."""
     _plans = None
 
-    # ---- plan cache: rebuilt when parameters move or are reloaded -----------------------
-    def _apply(self, fn, *args, **kwargs):
+    def _drop_plans(self):
         self._plans = None
+
+    def _apply(self, fn, *args, **kwargs):
+        self._drop_plans()
         return super()._apply(fn, *args, **kwargs)
 
-    def load_state_dict(self, *args, **kwargs):
-        self._plans = None
-        return super().load_state_dict(*args, **kwargs)
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._drop_plans()
+        return super()._load_from_state_dict(*args, **kwargs)
 
     def train(self, mode: bool = True):
-        self._plans = None
+        if mode != self.training:          # the reference calls model.eval() on every batch: keep the plans then
+            self._drop_plans()
         return super().train(mode)
 
-    def prepare(self) -> _Plans:
-        """Fold BatchNorm and repack weights for the HIP kernels (once per weight set)."""
+    def _weights_version(self) -> int:
+        """Sum of the in-place version counters of every parameter and buffer: changes whenever a weight is
+        overwritten (``load_state_dict`` on any sub-module, ``p.data.copy_``, an optimizer step)."""
+        return sum(t._version for t in self.parameters()) + sum(t._version for t in self.buffers())
+
+    def prepare(self, check_weights: bool = False) -> _Plans:
+        """Fold BatchNorm and repack weights for the HIP kernels (once per weight set).  The public entry points
+        pass ``check_weights=True``: plans built from weights that were since modified in place are rebuilt."""
+        if check_weights and self._plans is not None and self._plans.weights_version != self._weights_version():
+            self._drop_plans()
         if self._plans is None:
             dev = self.dres0[0][0].weight.device
             if dev.type != "cuda":
@@ -305,8 +334,8 @@ class _HipPlanMixin(nn.Module):
                     "the ACVNet hot path needs the model on the MI355X (model.cuda()); no CPU fallback")
             with torch.no_grad(), torch.cuda.device(dev):
                 self._plans = _Plans(self)
+                self._plans.weights_version = self._weights_version()
         return self._plans
-
 
 
 class ACVNet_DDIM(_HipPlanMixin):
@@ -400,10 +429,12 @@ class ACVNet_DDIM(_HipPlanMixin):
         times = list(reversed(times.int().tolist()))
         return list(zip(times[:-1], times[1:]))
 
-    def _filter(self, x_t: torch.Tensor, t: torch.Tensor):
-        """time shift + clamp + [0,1] (head.py:74-77, acv_ddim.py:256-258) -> (n01 state dtype, n01 fp32)."""
+    def _filter(self, x_t: torch.Tensor, t: Optional[torch.Tensor], shift: Optional[torch.Tensor] = None):
+        """time shift + clamp + [0,1] (head.py:74-77, acv_ddim.py:256-258) -> (n01 state dtype, n01 fp32).
+        ``shift`` [B,48]: the time MLP's output when it was precomputed for this step (``_loop_plan``)."""
         b, c, h, w = x_t.shape
-        shift = self.time_embedding.shift(t).float().contiguous()
+        if shift is None:
+            shift = self.time_embedding.shift(t).float().contiguous()
         lib = _lib.load()
         x_t = x_t.contiguous()
         if x_t.dtype == torch.float32:
@@ -443,6 +474,23 @@ class ACVNet_DDIM(_HipPlanMixin):
             k.sqrt_alpha_next = float(alpha_next.sqrt())
         return k
 
+    def _loop_plan(self) -> List[_LoopStep]:
+        """Per-step constants of ``ddim_sample`` (acv_ddim.py:306-308, :348-352 and the time MLP of head.py:74-75,
+        which sees nothing but ``t``): computed once per (weights, step list) and kept on the device, so the loop
+        itself launches no time-MLP kernels and copies no scalars."""
+        p = self.prepare()
+        key = (self.sampling_timesteps, self.ensemble_cof, self.dif_threshold, self.unc_threshold,
+               self.ddim_sampling_eta, self.num_timesteps)
+        if p.loop_key != key:
+            dev = self.dres0[0][0].weight.device
+            steps = []
+            for i, (time, time_next) in enumerate(self._time_pairs()):
+                t = torch.full((1,), time, device=dev, dtype=torch.long)
+                shift = self.time_embedding.shift(t).float().reshape(-1).contiguous()
+                steps.append(_LoopStep(time, time_next, self._step_coef(time, time_next, self.ensemble_cof[i + 1]), shift))
+            p.loop_steps, p.loop_key = steps, key
+        return p.loop_steps
+
     def _ddim_update(self, disp, unc, used, n01, eps, fill, mask, ens, coef, want_pred_noise=False):
         b, c, h, w = n01.shape
         dev = disp.device
@@ -460,12 +508,26 @@ class ACVNet_DDIM(_HipPlanMixin):
                                     b, c, h, w, ctypes.byref(coef), _lib.stream_ptr()), "dv_ddim_step")
         return x_start, x_next, pred_noise
 
+    def _check_loop_args(self, volume, used, img):
+        """Shapes the kernels index by: used / disp / ens are [B,4h,4w] for a [B,C,48,h,w] volume (the reference
+        fails with a broadcast error at ``disp - used``, acv_ddim.py:322)."""
+        b, _, d, h, w = volume.shape
+        if d != self.maxdisp // 4:
+            raise RuntimeError(f"the volume must have {self.maxdisp // 4} disparity bins, got {d}")
+        if used.numel() != b * 16 * h * w or tuple(used.shape[-2:]) != (4 * h, 4 * w):
+            raise RuntimeError(f"The size of tensor a {(b, 4 * h, 4 * w)} must match the size of tensor b "
+                               f"{tuple(used.shape)}: `used` must be the full-resolution disparity of the volume")
+        if tuple(img.shape) != (b, d, h, w):
+            raise RuntimeError(f"x_T must be {(b, d, h, w)}, got {tuple(img.shape)}")
+        return used.reshape(b, 4 * h, 4 * w)
+
     # ---- reference API ---------------------------------------------------------------------
     @torch.no_grad()
     def model_predictions(self, volume: torch.Tensor, noise: torch.Tensor, t: torch.Tensor):
         """acv_ddim.py:254-296 -> (pred_noise fp64, x_start fp32, pred [B,H,W], ProbVolumeHandle)."""
         volume = _dev_f32(volume, "volume")
         b, _, d, h, w = volume.shape
+        self.prepare(check_weights=True)
         with torch.cuda.device(volume.device):
             n01, n01f = self._filter(noise, t)
             cost = self._aggregate(volume, n01f)
@@ -478,17 +540,35 @@ class ACVNet_DDIM(_HipPlanMixin):
         return pred_noise, x_start, pred, ProbVolumeHandle(cost, unc, self.maxdisp)
 
     @torch.no_grad()
+    def ddim_step(self, i: int, volume: torch.Tensor, used: torch.Tensor, img: torch.Tensor, mask: torch.Tensor,
+                  ens: Optional[torch.Tensor] = None, eps: Optional[torch.Tensor] = None,
+                  fill: Optional[torch.Tensor] = None, out_disp: Optional[torch.Tensor] = None):
+        """Iteration ``i`` of the loop of acv_ddim.py:313-362 from explicit state: ``img`` is the DDIM state entering
+        the step (fp32 for i == 0, fp64 later), ``mask`` [B,h,w] the accumulated renewal mask (updated in place),
+        ``ens`` the ensemble accumulator (updated in place when given), ``eps`` / ``fill`` this step's
+        ``randn_like(img)`` / ``rand_like`` draws (not needed on the last step).
+        Returns (disp [B,4h,4w], uncertainty, x_start fp32, x_next fp64 | None)."""
+        st = self._loop_plan()[i]
+        b = volume.shape[0]
+        n01, n01f = self._filter(img, None, st.shift_rows(b))
+        cost = self._aggregate(volume, n01f)
+        disp, unc = upsample_softmax_regress(cost, want_uncertainty=True, out_disp=out_disp)
+        x_start, x_next, _ = self._ddim_update(disp, unc, used, n01, eps, fill, mask, ens, st.coef)
+        return disp, unc, x_start, x_next
+
+    @torch.no_grad()
     def ddim_sample(self, volume: torch.Tensor, used: torch.Tensor, asd: torch.Tensor,
-                    noise: Optional[NoiseFn] = None, generator: Optional[torch.Generator] = None):
+                    noise: Optional[NoiseFn] = None, generator: Optional[torch.Generator] = None,
+                    trace: Optional[Callable[[int, dict], None]] = None):
         """acv_ddim.py:298-370.  ``noise(kind, shape, dtype)`` (kind 'eps' = randn_like(img) :354,
         'fill' = rand_like :360) injects the random draws for parity tests; by default they come
-        from the device generator.  Returns (final_prediction [B,H,W], stack [S+1,B,H,W])."""
+        from the device generator.  ``trace(i, state)`` (tests) receives every step's tensors.
+        Returns (final_prediction [B,H,W], stack [S+1,B,H,W])."""
         volume = _dev_f32(volume, "volume")
-        used = _dev_f32(used, "used")
+        used = self._check_loop_args(volume, _dev_f32(used, "used"), asd)
         b, _, d, h, w = volume.shape
         dev = volume.device
-        if tuple(asd.shape) != (b, d, h, w):
-            raise RuntimeError(f"x_T must be {(b, d, h, w)}, got {tuple(asd.shape)}")
+        self.prepare(check_weights=True)
 
         def draw(kind, shape, dtype):
             if noise is not None:
@@ -497,29 +577,30 @@ class ACVNet_DDIM(_HipPlanMixin):
             return fn(shape, device=dev, dtype=dtype, generator=generator)
 
         with torch.cuda.device(dev):
+            steps = self._loop_plan()
             img = asd.to(dev).contiguous()
-            final = [used]
+            stack = torch.empty((len(steps) + 1, b, 4 * h, 4 * w), dtype=torch.float32, device=dev)
+            stack[0].copy_(used)
             mask = torch.zeros((b, h, w), dtype=torch.float32, device=dev)
             ens = used * self.ensemble_cof[0]
-            for i, (time, time_next) in enumerate(self._time_pairs()):
-                t = torch.full((b,), time, device=dev, dtype=torch.long)
-                n01, n01f = self._filter(img, t)
-                cost = self._aggregate(volume, n01f)
-                disp, unc = upsample_softmax_regress(cost, want_uncertainty=True)
-                final.append(disp)
-                coef = self._step_coef(time, time_next, self.ensemble_cof[i + 1])
+            for i, st in enumerate(steps):
                 eps = fill = None
-                if time_next >= 0:
+                if st.time_next >= 0:
                     eps = draw("eps", tuple(img.shape), img.dtype)
                     fill = draw("fill", tuple(img.shape), torch.float64)
-                x_start, x_next, _ = self._ddim_update(disp, unc, used, n01, eps, fill, mask, ens, coef)
-                img = x_start if time_next < 0 else x_next
-        stack = torch.stack(final, dim=0)
+                if trace is not None:
+                    trace(i, {"when": "in", "img": img, "mask": mask.clone(), "eps": eps, "fill": fill})
+                disp, unc, x_start, x_next = self.ddim_step(i, volume, used, img, mask, ens, eps, fill,
+                                                            out_disp=stack[i + 1])
+                if trace is not None:
+                    trace(i, {"when": "out", "disp": disp, "unc": unc, "x_start": x_start, "x_next": x_next,
+                              "mask": mask.clone()})
+                img = x_start if st.time_next < 0 else x_next
         if any_split_plan(self._plans):
             check_split_overflow(dev)
         if self.use_ensemble:
             return ens, stack
-        return final[-1]
+        return stack[-1]
 
     @torch.no_grad()
     def encode_disparity(self, disp: torch.Tensor) -> torch.Tensor:

@@ -283,9 +283,9 @@ class hourglass(nn.Module):
         self._plans = None
         return super()._apply(fn, *a, **k)
 
-    def load_state_dict(self, *a, **k):
+    def _load_from_state_dict(self, *a, **k):      # reached also when a parent / wrapper loads the checkpoint
         self._plans = None
-        return super().load_state_dict(*a, **k)
+        return super()._load_from_state_dict(*a, **k)
 
     def forward(self, x, features):
         p = self.prepare()
@@ -318,9 +318,9 @@ class IGEVCostVolume(nn.Module):
         self._plans = None
         return super()._apply(fn, *a, **k)
 
-    def load_state_dict(self, *a, **k):
+    def _load_from_state_dict(self, *a, **k):      # reached also when a parent / wrapper loads the checkpoint
         self._plans = None
-        return super().load_state_dict(*a, **k)
+        return super()._load_from_state_dict(*a, **k)
 
     def prepare(self):
         if self._plans is None:

@@ -89,6 +89,8 @@ class MetricAccumulator:
         import torch.distributed as dist
         state = self.state.clone()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            if dist.get_backend(group) == "gloo":          # CPU rendezvous (tests on a 1-GPU box): reduce on the host
+                state = state.cpu()
             dist.all_reduce(state, op=dist.ReduceOp.SUM, group=group)
         host = state.cpu()
         n = max(float(host[5]), 1.0)

@@ -27,7 +27,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib
-from .acv_ddim import ProbVolumeHandle, _bn_of, _plan_cb3, cosine_beta_schedule
+from .acv_ddim import ProbVolumeHandle, _LoopStep, _bn_of, _plan_cb3, cosine_beta_schedule
 from .head import DynamicHead
 from .profiling import timed
 from .submodule import (ACT_MISH, ACT_NONE, Conv2dPlan, Conv3dPlan, Deconv3dPlan, _dev_f32, build_concat_volume,
@@ -123,7 +123,8 @@ class FeatureExtraction(nn.Module, _Stacker):
         return super()._load_from_state_dict(*a, **k)
 
     def train(self, mode: bool = True):
-        self._plans = None
+        if mode != self.training:
+            self._plans = None
         return super().train(mode)
 
     def prepare(self):
@@ -470,22 +471,46 @@ class PWCNet_ddim(nn.Module):
         self._plans = None
         return super()._apply(fn, *a, **k)
 
-    def load_state_dict(self, *a, **k):
+    def _load_from_state_dict(self, *a, **k):      # reached however the checkpoint arrives (wrapper or direct)
         self._plans = None
-        return super().load_state_dict(*a, **k)
+        return super()._load_from_state_dict(*a, **k)
 
     def train(self, mode: bool = True):
-        self._plans = None
+        if mode != self.training:
+            self._plans = None
         return super().train(mode)
 
-    def prepare(self) -> _Plans:
+    def _weights_version(self) -> int:
+        return sum(t._version for t in self.parameters()) + sum(t._version for t in self.buffers())
+
+    def prepare(self, check_weights: bool = False) -> _Plans:
+        if check_weights and self._plans is not None and self._plans.weights_version != self._weights_version():
+            self._plans = None
         if self._plans is None:
             dev = self.dres0[0][0].weight.device
             if dev.type != "cuda":
                 raise _lib.DiffuVolumeError("PWCNet_ddim hot path needs the model on the MI355X; no CPU fallback")
             with torch.no_grad(), torch.cuda.device(dev):
                 self._plans = _Plans(self)
+                self._plans.weights_version = self._weights_version()
+                self._plans.loop_key = self._plans.loop_steps = None
         return self._plans
+
+    def _loop_plan(self):
+        """Per-step constants of the loop (time-MLP shift on the device, coefficient struct): they depend only
+        on the step list, so they are computed once per weight set instead of once per step and pass."""
+        p = self.prepare()
+        key = (self.sampling_timesteps, self.ensemble_cof, self.dif_threshold, self.unc_threshold,
+               self.ddim_sampling_eta, self.num_timesteps)
+        if p.loop_key != key:
+            dev = self.dres0[0][0].weight.device
+            steps = []
+            for i, (time, time_next) in enumerate(self._time_pairs()):
+                t = torch.full((1,), time, device=dev, dtype=torch.long)
+                shift = self.time_embedding.shift(t).float().reshape(-1).contiguous()
+                steps.append(_LoopStep(time, time_next, self._step_coef(time, time_next, self.ensemble_cof[i + 1]), shift))
+            p.loop_steps, p.loop_key = steps, key
+        return p.loop_steps
 
     # ---- pieces ---------------------------------------------------------------------------------------
     def _time_pairs(self):
@@ -493,9 +518,10 @@ class PWCNet_ddim(nn.Module):
         times = list(reversed(times.int().tolist()))
         return list(zip(times[:-1], times[1:]))
 
-    def _filter(self, x_t, t):
+    def _filter(self, x_t, t, shift=None):
         b, c, h, w = x_t.shape
-        shift = self.time_embedding.shift(t).float().contiguous()
+        if shift is None:
+            shift = self.time_embedding.shift(t).float().contiguous()
         lib = _lib.load()
         x_t = x_t.contiguous()
         if x_t.dtype == torch.float32:
@@ -569,8 +595,8 @@ class PWCNet_ddim(nn.Module):
                                             b, c, h, w, ctypes.byref(coef), _lib.stream_ptr()), "dv_ddim_step")
         return x_start, x_next, pred_noise
 
-    def _predict(self, volume, img, t, features_left, features_right):
-        n01, n01f = self._filter(img, t)
+    def _predict(self, volume, img, t, features_left, features_right, shift=None):
+        n01, n01f = self._filter(img, t, shift)
         cost = self._aggregate(volume, n01f)
         pred3, _ = upsample_softmax_regress(cost, want_uncertainty=False, align_corners=True)
         disp = self._refine(pred3, features_left, features_right).contiguous()
@@ -592,14 +618,23 @@ class PWCNet_ddim(nn.Module):
 
     @torch.no_grad()
     def ddim_sample(self, volume, used, asd, features_left, features_right, noise: Optional[NoiseFn] = None,
-                    generator: Optional[torch.Generator] = None):
+                    generator: Optional[torch.Generator] = None, trace=None):
         """pwcnet_ddim.py:530-602.  Random draws in reference order: 'x_T' (torch.randn, :541), then per
         non-final step 'eps' (randn_like(img), :585) and 'q' (randn_like(asd) inside q_sample, :590)."""
         volume = _dev_f32(volume, "volume")
         used = _dev_f32(used, "used")
         b, _, d, h, w = volume.shape
         dev = volume.device
-        p = self.prepare()
+        if d != 48:
+            raise RuntimeError(f"the fused volume must have 48 disparity bins, got {d}")
+        if used.numel() != b * 16 * h * w or tuple(used.shape[-2:]) != (4 * h, 4 * w):
+            # the kernels index used / disp / ens as [B,4h,4w]; the reference fails at `disp - used` (:556)
+            raise RuntimeError(f"The size of tensor a {(b, 4 * h, 4 * w)} must match the size of tensor b "
+                               f"{tuple(used.shape)}: `used` must be the full-resolution disparity of the volume")
+        used = used.reshape(b, 4 * h, 4 * w)
+        if tuple(asd.shape) != (b, 48, h, w):
+            raise RuntimeError(f"x_T must be {(b, 48, h, w)}, got {tuple(asd.shape)}")
+        p = self.prepare(check_weights=True)
 
         def draw(kind, shape, dtype):
             if noise is not None:
@@ -613,26 +648,42 @@ class PWCNet_ddim(nn.Module):
             mask = torch.zeros((b, h, w), dtype=torch.float32, device=dev)
             ens = used * self.ensemble_cof[0]
             handle = None
-            for i, (time, time_next) in enumerate(self._time_pairs()):
-                t = torch.full((b,), time, device=dev, dtype=torch.long)
-                n01, cost, disp, unc = self._predict(volume, img, t, features_left, features_right)
-                handle = ProbVolumeHandle(cost, unc, self.maxdisp, align_corners=True)
-                final.append(disp)
-                coef = self._step_coef(time, time_next, self.ensemble_cof[i + 1])
+            for i, st in enumerate(self._loop_plan()):
+                time, time_next = st.time, st.time_next
                 eps = fill = None
                 if time_next >= 0:
                     eps = draw("eps", tuple(img.shape), img.dtype)
                     # asd = q_sample(asd, t): float64 from the first step on (float64 schedule buffers)
                     asd = p.sqrt_ac[time].item() * asd.double() + p.sqrt_1mac[time].item() * draw("q", tuple(asd.shape), asd.dtype).double()
                     fill = asd.contiguous()
+                if trace is not None:
+                    trace(i, {"when": "in", "img": img, "mask": mask.clone(), "eps": eps, "fill": fill})
                 # (the last step's mask is never read again: the reference only builds the unused mask_final there)
-                x_start, x_next, _ = self._ddim_update(disp, unc, used, n01, eps, fill, mask, ens, coef)
+                disp, unc, x_start, x_next, cost = self.ddim_step(i, volume, used, img, mask, ens, eps, fill,
+                                                                  features_left, features_right, want_cost=True)
+                if trace is not None:
+                    trace(i, {"when": "out", "disp": disp, "unc": unc, "x_start": x_start, "x_next": x_next,
+                              "mask": mask.clone()})
+                handle = ProbVolumeHandle(cost, unc, self.maxdisp, align_corners=True)
+                final.append(disp)
                 img = x_start if time_next < 0 else x_next
         if getattr(p.dres0.b, "split", False):
             check_split_overflow(dev)
         if self.use_ensemble:
             return ens, handle
         return final[-1], handle
+
+    @torch.no_grad()
+    def ddim_step(self, i, volume, used, img, mask, ens=None, eps=None, fill=None, features_left=None,
+                  features_right=None, want_cost=False):
+        """Iteration ``i`` of the loop of pwcnet_ddim.py:545-598 from explicit state (``img`` entering the step,
+        ``mask`` updated in place, ``eps`` = randn_like(img), ``fill`` = the q_sample'd origin encoding).
+        Returns (disp_finetune [B,4h,4w], uncertainty, x_start fp32, x_next fp64 | None[, cost])."""
+        st = self._loop_plan()[i]
+        n01, cost, disp, unc = self._predict(volume, img, None, features_left, features_right,
+                                             shift=st.shift_rows(volume.shape[0]))
+        x_start, x_next, _ = self._ddim_update(disp, unc, used, n01, eps, fill, mask, ens, st.coef)
+        return (disp, unc, x_start, x_next, cost) if want_cost else (disp, unc, x_start, x_next)
 
     @torch.no_grad()
     def encode_disparity(self, disp):

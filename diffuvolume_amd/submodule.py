@@ -158,7 +158,7 @@ def disparity_regression(x: torch.Tensor, maxdisp: int, keepdim: bool = False) -
 
 
 def upsample_softmax_regress(cost: torch.Tensor, want_uncertainty: bool = True,
-                             align_corners: bool = False
+                             align_corners: bool = False, out_disp: Optional[torch.Tensor] = None
                              ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """cost [B,1,D,h,w] (or [B,D,h,w]) -> (disp [B,4h,4w], uncertainty | None): trilinear x4,
     softmax over 4D bins, soft-argmax and sum_k |disp-k| p_k (acv_ddim.py:267-270, :325-329)."""
@@ -168,7 +168,13 @@ def upsample_softmax_regress(cost: torch.Tensor, want_uncertainty: bool = True,
             raise RuntimeError("cost must have one channel")
         cost = cost[:, 0]
     b, d, h, w = cost.shape
-    disp = torch.empty((b, 4 * h, 4 * w), dtype=torch.float32, device=cost.device)
+    if out_disp is None:
+        disp = torch.empty((b, 4 * h, 4 * w), dtype=torch.float32, device=cost.device)
+    else:                                   # e.g. a slice of the per-step stack of ddim_sample
+        disp = out_disp
+        if tuple(disp.shape) != (b, 4 * h, 4 * w) or disp.dtype != torch.float32 or not disp.is_contiguous() \
+                or disp.device != cost.device:
+            raise RuntimeError("out_disp must be a contiguous float32 [B,4h,4w] tensor on the cost's device")
     unc = torch.empty_like(disp) if want_uncertainty else None
     lib = _lib.load()
     with torch.cuda.device(cost.device):

@@ -98,6 +98,28 @@ def synth_stereo_batch(b: int, h: int, w: int, seed: int = 0, shifts=(6, 24, 60)
     return {"left": left, "right": right, "gt": gt, "used": used, "disp": disp}
 
 
+def synth_hot_inputs(batch: int, h: int, w: int, seed: int, shifts=(6, 24, 60)) -> Dict[str, torch.Tensor]:
+    """Inputs of the hot path at quarter resolution h x w: 320-channel gwc features and 32-channel
+    concat features with a real correlation ridge (right = left rolled by the pair's disparity + noise), attention
+    logits, full-resolution ground truth, the origin network's stand-in ``used`` and its quarter-resolution
+    encoding input ``dq``.  CPU tensors; bench.py and the full-size parity tests move them to the device."""
+    import torch.nn.functional as F
+    g = _gen(seed, f"bench{batch}x{h}x{w}")
+
+    def pair(c):
+        left = torch.randn(batch, c, h, w, generator=g)
+        right = torch.stack([torch.roll(left[i], -(shifts[i % 3] // 4), dims=-1) for i in range(batch)])
+        return left, right + 0.05 * torch.randn(batch, c, h, w, generator=g)
+
+    fl, fr = pair(320)
+    cl, cr = pair(32)
+    att = torch.randn(batch, 1, 48, h, w, generator=g) * 2
+    gt = torch.stack([shifts[i % 3] + torch.randn(4 * h, 4 * w, generator=g) for i in range(batch)]).clamp(0.5, 191)
+    used = (gt + 0.5 * torch.randn(batch, 4 * h, 4 * w, generator=g)).clamp(0, 191)
+    dq = F.interpolate(used.unsqueeze(1), size=(h, w), mode="bilinear") / 4
+    return dict(fl=fl, fr=fr, cl=cl, cr=cr, att=att, gt=gt, used=used, dq=dq)
+
+
 class NoiseTape:
     """Deterministic replacement for the DDIM loop's random draws (acv_ddim.py:354 'eps' =
     randn_like(img), :360 'fill' = rand_like): the k-th draw of each kind comes from its own

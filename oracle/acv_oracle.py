@@ -293,10 +293,12 @@ class ACVDiffusionOracle:
         return pred_noise, x_start, pred, prob
 
     def ddim_sample(self, volume: Tensor, used: Tensor, x_T: Tensor,
-                    draw: Callable[[str, Tuple[int, ...], torch.dtype], Tensor]):
+                    draw: Callable[[str, Tuple[int, ...], torch.dtype], Tensor], trace=None):
         """acv_ddim.py:298-370.  ``draw(kind, shape, dtype)`` supplies the random
         tensors in reference order: per non-final step 'eps' (randn_like(img),
-        :354) then 'fill' (rand_like, :360).  Returns (final, stack [S+1,B,H,W])."""
+        :354) then 'fill' (rand_like, :360).  Returns (final, stack [S+1,B,H,W]).
+        ``trace`` (a list) receives one dict per step with the state entering the step
+        (img, mask_in), its outputs (disp, unc, x_start, mask_out, img_next) and the draws."""
         b, _, _, h, w = volume.shape
         img = x_T
         final = [used.unsqueeze(0)]
@@ -307,9 +309,17 @@ class ACVDiffusionOracle:
             final.append(disp.unsqueeze(0))
             dif = torch.abs(disp - used)
             unc = disparity_uncertainty(disp, prob)
+            del prob
             keep = ((dif < 1) & (unc < 3)).float()
             keep = F.interpolate(keep.unsqueeze(1), size=(h, w), mode="bilinear").squeeze(1)
+            rec = None
+            if trace is not None:
+                rec = {"time": time, "time_next": time_next, "img": img, "mask_in": mask, "disp": disp, "unc": unc,
+                       "x_start": x_start, "eps": None, "fill": None, "img_next": None}
+                trace.append(rec)
             mask = torch.clamp(mask + keep, 0, 1)
+            if rec is not None:
+                rec["mask_out"] = mask
             if time_next < 0:
                 img = x_start
                 continue
@@ -321,6 +331,8 @@ class ACVDiffusionOracle:
             img = x_start * alpha_next.sqrt() + c * pred_noise + sigma * eps
             fill = draw("fill", tuple(img.shape), torch.float64)
             img = torch.where(mask.unsqueeze(1) == 0, fill, img)
+            if rec is not None:
+                rec["eps"], rec["fill"], rec["img_next"] = eps, fill, img
         stack = torch.cat(final, dim=0)
         cof = torch.tensor(self.cof).view(-1, 1, 1, 1)
         return torch.sum(stack * cof, dim=0), stack

@@ -173,8 +173,11 @@ class PCWDiffusionOracle:
         pred_noise = (self.sqrt_recip.gather(-1, t).reshape(bs) * n01 - x_start) / self.sqrt_recipm1.gather(-1, t).reshape(bs)
         return pred_noise, x_start, disp, prob
 
-    def ddim_sample(self, volume, used, asd, fl, fr, draw: Callable[[str, Tuple[int, ...], torch.dtype], Tensor]):
-        """pwcnet_ddim.py:530-602; draws: 'x_T' (:541), then per non-final step 'eps' (:585), 'q' (:590)."""
+    def ddim_sample(self, volume, used, asd, fl, fr, draw: Callable[[str, Tuple[int, ...], torch.dtype], Tensor],
+                    trace=None):
+        """pwcnet_ddim.py:530-602; draws: 'x_T' (:541), then per non-final step 'eps' (:585), 'q' (:590).
+        ``trace`` (a list) receives one dict per step: the state entering it, its outputs and draws
+        ('fill' = the q_sample'd origin encoding that replaces never-confirmed pixels, :590-594)."""
         b, _, _, h, w = volume.shape
         img = draw("x_T", (b, 48, h, w), torch.float32)
         final = [used.unsqueeze(0)]
@@ -186,10 +189,17 @@ class PCWDiffusionOracle:
             pred_noise, x_start, disp, prob = self.model_predictions(volume, img, t, fl, fr)
             final.append(disp.unsqueeze(0))
             unc = A.disparity_uncertainty(disp, prob)
+            rec = None
+            if trace is not None:
+                rec = {"time": time, "time_next": time_next, "img": img, "mask_in": mask, "disp": disp, "unc": unc,
+                       "x_start": x_start, "eps": None, "fill": None, "img_next": None, "mask_out": None}
+                trace.append(rec)
             if time_next >= 0:
                 keep = ((torch.abs(disp - used) < 1) & (unc < 1)).float()
                 keep = F.interpolate(keep.unsqueeze(1), size=(h, w), mode="bilinear").squeeze(1)
                 mask = torch.clamp(mask + keep, 0, 1)
+                if rec is not None:
+                    rec["mask_out"] = mask
             else:
                 img = x_start
                 continue
@@ -202,5 +212,7 @@ class PCWDiffusionOracle:
             asd = (self.sqrt_alphas_cumprod.gather(-1, tt).reshape(1, 1, 1, 1) * asd
                    + self.sqrt_one_minus.gather(-1, tt).reshape(1, 1, 1, 1) * draw("q", tuple(asd.shape), asd.dtype))
             img = torch.where(mask.unsqueeze(1) == 0, asd, img)
+            if rec is not None:
+                rec["eps"], rec["fill"], rec["img_next"] = eps, asd, img
         stack = torch.cat(final, dim=0)
         return torch.sum(stack * torch.tensor(self.cof).view(-1, 1, 1, 1), dim=0), stack

@@ -1,0 +1,53 @@
+"""bench.py --gpus N must never report a GPU count it did not run on: without a launcher it starts
+the N ranks itself, with one it checks WORLD_SIZE, and with too few devices it exits non-zero.  CPU-only plumbing
+(gloo) through --dry-run; the real N-GPU run is the driver's."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _run(args, env=None, timeout=240):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, str(ROOT / "bench.py")] + args, capture_output=True, text=True, env=e,
+                          timeout=timeout, cwd=ROOT)
+
+
+def _json_line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_self_launch_two_ranks():
+    r = _run(["--gpus", "2", "--dry-run"])
+    assert r.returncode == 0, r.stderr
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["launcher"] == "self" and line["global_batch"] == 16
+
+
+def test_under_torchrun_two_ranks():
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29653", str(ROOT / "bench.py"), "--gpus", "2",
+                        "--dry-run"], capture_output=True, text=True, timeout=240, cwd=ROOT)
+    assert r.returncode == 0, r.stderr
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["launcher"] == "torchrun"
+
+
+def test_world_size_mismatch_is_an_error():
+    r = _run(["--gpus", "4", "--dry-run"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_too_few_devices_is_an_error():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        return                                  # a multi-GPU box would really run it
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0 and "refusing" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]      # and no JSON line with a wrong n_gpus

@@ -324,7 +324,7 @@ def test_aggregation_cost_parity(model, acv_state_dict):
 
 
 def test_model_predictions_golden(model):
-    """One volume-filter step: disparity within 1e-3 px of the reference on 99% of the pixels and
+    """One volume-filter step: disparity within 1e-3 px of the reference on 99.9 % of the pixels and
     ~1e-4 px on average (north-star bar).  The soft-argmax amplifies cost error by the spread of the
     distribution, |d disp| <= unc * max|d cost|; with random weights the spread is large, hence the
     separate bars for the mean, the 99th percentile and the tail."""
@@ -332,9 +332,12 @@ def test_model_predictions_golden(model):
     pn, xs, pred, handle = model.model_predictions(dev(_volume(g["vol_seed"])), dev(g["x_T"]), dev(g["t"]))
     assert pn.dtype == torch.float64 and xs.dtype == torch.float32
     d = (pred.cpu() - g["pred"]).abs()
-    assert float(d.mean()) < 2e-4 and float((d > 1e-3).float().mean()) < 1e-2, (float(d.mean()), float(d.max()))
+    # north-star bars against the reference's own output: 99.9 % of the pixels within 1e-3 px, EPE within 1e-4
+    assert float(d.mean()) < 2e-4 and float((d > 1e-3).float().mean()) <= 1e-3, (float(d.mean()), float(d.max()))
+    gt = g["used0"].reshape(g["pred"].shape)             # EPE against the fixture's origin disparity
+    assert abs(float((pred.cpu() - gt).abs().mean()) - float((g["pred"] - gt).abs().mean())) < 1e-4
     p99 = float(d.flatten().quantile(0.99))
-    assert p99 < 2e-3, p99
+    assert p99 < 1e-3, p99
     du = (handle.uncertainty.cpu() - g["unc"]).abs()
     assert float(du.mean()) < 1e-3
     # the two-hot re-encoding moves with the disparity (weights) and flips bins only where floor() flips
@@ -344,38 +347,61 @@ def test_model_predictions_golden(model):
     torch.testing.assert_close(pn.cpu()[sel], g["pred_noise"][sel], atol=1e-6, rtol=0)
 
 
-def _loop_errors(model, sd, vol, used, x_T, seed):
-    """(HIP, fp32 oracle) error of every DDIM step against a float64 run of the oracle."""
+def _assert_loop_contract(model, sd, vol, used, x_T, seed, gt=None):
+    """The north-star bars on the 5-step loop (|d disp| <= 1e-3 px on 99.9 % of the pixels, |EPE_hip - EPE_oracle|
+    < 1e-4 px), asserted where they are well defined (oracle/loop_parity.py): every step from the oracle's own state
+    (teacher forced) and HIP's own state under the oracle's renewal decisions (decision forced); a free-run step may
+    leave the bar only after a renewal decision has come out differently.  Returns the report."""
+    from oracle import loop_parity as LP
+    gt = used if gt is None else gt                     # fixtures without ground truth: EPE against `used`
+    orc = O.ACVDiffusionOracle(sd)
+    final_o, stack_o, trace = LP.oracle_trajectory(orc, vol, used, x_T, seed)
+    vol_d, used_d = dev(vol), dev(used)
+    npx = stack_o[0].numel()
+    bar = max(LP.BAR_FRAC, 1.0 / npx)                  # "99.9 %" of a fixture smaller than 1000 px means one pixel
+    tf = LP.teacher_forced(model, trace, vol_d, used_d, used, gt)
+    df = LP.decision_forced(model, trace, vol_d, used_d, x_T, gt)
+    fr = LP.free_run(model, trace, stack_o, final_o, vol_d, used_d, x_T, gt, seed)
+    for s in tf + df:
+        assert s["frac_gt_1e-3"] <= bar, s
+        assert s["epe_delta"] < LP.BAR_EPE, s
+    for s in tf:
+        if "x_next_mean_abs_where_decisions_agree" in s:
+            assert s["x_next_mean_abs_where_decisions_agree"] < 1e-4, s
+    flips = 0
+    for s in fr["steps"]:
+        assert s["frac_gt_1e-3"] <= bar or flips > 0, s
+        flips += s["flips_mask_zero"]
+    if flips == 0:
+        assert fr["final"]["epe_delta"] < LP.BAR_EPE, fr["final"]
+    return {"teacher_forced": tf, "decision_forced": df, "free_run": fr, "flips": flips}
+
+
+def _teacher_forced_vs_fp64(model, sd, vol, used, x_T, seed):
+    """Per step, from the state of a float64 run of the oracle: mean |d disp| of (HIP, fp32 oracle) against the
+    float64 step.  Separates arithmetic error from the loop's decision chaos (VERDICT r1, weak #1)."""
+    from oracle import loop_parity as LP
     orc, orc64 = O.ACVDiffusionOracle(sd), O.ACVDiffusionOracle(_f64_state_dict(sd))
-    f32, s32 = orc.ddim_sample(vol, used, x_T, NoiseTape(seed))
-    f64, s64 = orc64.ddim_sample(vol.double(), used.double(), x_T, NoiseTape(seed))
-    fh, sh = model.ddim_sample(dev(vol), dev(used), dev(x_T), noise=NoiseTape(seed))
-    e_h = (sh.cpu().double() - s64).abs()
-    e_o = (s32.double() - s64).abs()
-    return e_h, e_o, (fh.cpu().double() - f64).abs(), (f32.double() - f64).abs()
-
-
-def _check_loop(e_h, e_o, ef_h, ef_o):
-    """e_*: per-step |err| vs the float64 run (HIP / fp32 oracle).  Early steps: HIP within 3x of the
-    fp32 oracle's own error.  Later steps feed floor()/threshold flips back into the state, the error
-    of BOTH grows chaotically and their ratio is no longer stable: bound the median tightly and the
-    mean by an order of magnitude."""
-    for i in range(1, e_h.shape[0]):
-        eh, eo = float(e_h[i].mean()), float(e_o[i].mean())
-        assert float(e_h[i].median()) < 1e-4, (i, float(e_h[i].median()))
-        if i <= 2:
-            assert eh < 3 * eo + 5e-5, (i, eh, eo)
-        assert eh < 10 * eo + 2e-4, (i, eh, eo)
-    assert float(ef_h.median()) < 1e-4
-    assert float(ef_h.mean()) < 10 * float(ef_o.mean()) + 2e-4
+    _, _, trace = LP.oracle_trajectory(orc64, vol.double(), used.double(), x_T, seed)
+    vol_d, used_d = dev(vol), dev(used)
+    out = []
+    for i, r in enumerate(trace):
+        mask = dev(r["mask_in"]).clone()
+        eps = None if r["eps"] is None else dev(r["eps"])
+        fill = None if r["fill"] is None else dev(r["fill"])
+        disp_h = model.ddim_step(i, vol_d, used_d, dev(r["img"]), mask, None, eps, fill)[0].cpu()
+        t = torch.full((vol.shape[0],), r["time"], dtype=torch.long)
+        disp_o = orc.model_predictions(vol, r["img"], t)[2]
+        out.append((float((disp_h.double() - r["disp"]).abs().mean()), float((disp_o.double() - r["disp"]).abs().mean())))
+    return out
 
 
 def test_ddim_sample_golden(model, acv_state_dict):
-    """Five-step loop against the reference's own outputs.  The loop feeds floor()/threshold decisions
-    back into the state, so fp32 re-association noise grows step by step -- for the reference too:
-    its fp32 run differs from a float64 run by 7e-5 px (step 1) to 1.5e-3 px (step 5) on average
-    (measured).  Bars: the median pixel stays within 1e-4 px of the golden stack at every
-    step, and the HIP path is never more than 3x further from float64 than the fp32 oracle is."""
+    """Five-step loop.  (1) against the reference's own outputs (golden stack): the median pixel within 1e-4 px at
+    every step and step 1 -- before any decision has been fed back -- within the contract; (2) the contract bars on
+    all five steps against the oracle (which test_oracle_golden.py pins to that same golden stack to 99.9 %);
+    (3) arithmetic distance to a float64 evaluation, step by step from the same state: HIP is as close as the
+    fp32 oracle."""
     g = load_golden("ddim_sample")
     vol = _volume(g["vol_seed"])
     final, stack = model.ddim_sample(dev(vol), dev(g["used"]), dev(g["x_T"]), noise=NoiseTape(g["tape_seed"]))
@@ -384,9 +410,12 @@ def test_ddim_sample_golden(model, acv_state_dict):
     d = (stack.cpu() - g["stack"]).abs()
     for i in range(1, 6):
         assert float(d[i].median()) < 1e-4, (i, float(d[i].median()))
-    assert float(d[1].mean()) < 2e-4 and float((d[1] > 1e-3).float().mean()) < 1e-2
-    e_h, e_o, ef_h, ef_o = _loop_errors(model, acv_state_dict, vol, g["used"], g["x_T"], g["tape_seed"])
-    _check_loop(e_h, e_o, ef_h, ef_o)
+    assert float(d[1].mean()) < 2e-4 and float((d[1] > 1e-3).float().mean()) <= 1e-3, \
+        (float(d[1].mean()), float((d[1] > 1e-3).float().mean()))
+    rep = _assert_loop_contract(model, acv_state_dict, vol, g["used"], g["x_T"], g["tape_seed"])
+    print("ddim_sample fixture:", rep)
+    for i, (e_h, e_o) in enumerate(_teacher_forced_vs_fp64(model, acv_state_dict, vol, g["used"], g["x_T"], g["tape_seed"])):
+        assert e_h < 1.5 * e_o + 2e-5, (i + 1, e_h, e_o)
 
 
 def test_ddim_sample_vs_oracle_batch2(model, acv_state_dict):
@@ -396,24 +425,39 @@ def test_ddim_sample_vs_oracle_batch2(model, acv_state_dict):
     orc = O.ACVDiffusionOracle(acv_state_dict)
     dq = torch.nn.functional.interpolate(used.unsqueeze(1), size=(8, 16), mode="bilinear") / 4
     x_T = orc.encode_x_T(dq)
-    e_h, e_o, ef_h, ef_o = _loop_errors(model, acv_state_dict, vol, used, x_T, 5)
-    _check_loop(e_h, e_o, ef_h, ef_o)
+    _assert_loop_contract(model, acv_state_dict, vol, used, x_T, 5)
+    for i, (e_h, e_o) in enumerate(_teacher_forced_vs_fp64(model, acv_state_dict, vol, used, x_T, 5)):
+        assert e_h < 1.5 * e_o + 2e-5, (i + 1, e_h, e_o)
 
 
-def test_forward_golden(model):
+def test_forward_golden(model, acv_state_dict):
+    """ACVNet_DDIM.forward (eval) against the reference's output: median within 1e-4 px; the loop inside is then
+    held to the contract bars on the very volume forward() built (feature CNN + attention branch + builders on
+    HIP), so a difference in the front end cannot hide behind the loop's decision chaos."""
     g = load_golden("forward_eval")
     batch = synth_stereo_batch(1, 64, 128, seed=g["stereo_seed"], shifts=(8,))
     # forward() draws from the device RNG; inject the tape through ddim_sample
     tape = NoiseTape(g["tape_seed"])
     keep = model.ddim_sample
-    model.ddim_sample = lambda v, u, a, **kw: keep(v, u, a, noise=tape)
+    seen = {}
+
+    def spy(v, u, a, **kw):
+        seen["vol"], seen["x_T"] = v, a
+        return keep(v, u, a, noise=tape)
+
+    model.ddim_sample = spy
     try:
         pred = model(dev(batch["left"]), dev(batch["right"]), dev(batch["used"]), dev(batch["disp"]), None)[0]
     finally:
         del model.ddim_sample
     d = (pred.cpu() - g["pred"]).abs()
     assert float(d.median()) < 1e-4, float(d.median())
-    assert float(d.mean()) < 1e-2, float(d.mean())        # chaotic tail of the 5-step loop, see test_ddim_sample_golden
+    rep = _assert_loop_contract(model, acv_state_dict, seen["vol"].cpu(), batch["used"], seen["x_T"].cpu(),
+                                g["tape_seed"], gt=batch["gt"])
+    if rep["flips"] == 0:                      # no decision differs: the whole forward meets the contract vs the reference
+        assert float((d > 1e-3).float().mean()) <= 1e-3
+        gt, m = batch["gt"], (batch["gt"] > 0) & (batch["gt"] < 192)
+        assert abs(float((pred.cpu() - gt).abs()[m].mean()) - float((g["pred"] - gt).abs()[m].mean())) < 1e-4
 
 
 # ---------------------------------------------------------------- metrics
@@ -497,9 +541,10 @@ def test_ddim_loop_with_split_fp16_convs(acv_state_dict):
     d = (stack.cpu() - g["stack"]).abs()
     for i in range(1, 6):
         assert float(d[i].median()) < 1e-4, (i, float(d[i].median()))
-    assert float(d[1].mean()) < 2e-4 and float((d[1] > 1e-3).float().mean()) < 1e-2
-    e_h, e_o, ef_h, ef_o = _loop_errors(m, acv_state_dict, vol, g["used"], g["x_T"], g["tape_seed"])
-    _check_loop(e_h, e_o, ef_h, ef_o)
+    assert float(d[1].mean()) < 2e-4 and float((d[1] > 1e-3).float().mean()) <= 1e-3
+    _assert_loop_contract(m, acv_state_dict, vol, g["used"], g["x_T"], g["tape_seed"])
+    for i, (e_h, e_o) in enumerate(_teacher_forced_vs_fp64(m, acv_state_dict, vol, g["used"], g["x_T"], g["tape_seed"])):
+        assert e_h < 1.5 * e_o + 2e-5, (i + 1, e_h, e_o)
 
 
 def test_origin_acvnet_forward_golden():
@@ -722,17 +767,16 @@ def test_ddim_sample_other_step_counts(acv_state_dict, steps):
     orc, orc64 = O.ACVDiffusionOracle(acv_state_dict, sampling_timesteps=steps, cof=cof), O.ACVDiffusionOracle(sd64, sampling_timesteps=steps, cof=cof)
     dq = torch.nn.functional.interpolate(used.unsqueeze(1), size=(8, 16), mode="bilinear") / 4
     x_T = orc.encode_x_T(dq)
-    f32, s32 = orc.ddim_sample(vol, used, x_T, NoiseTape(7))
-    f64, s64 = orc64.ddim_sample(vol.double(), used.double(), x_T, NoiseTape(7))
+    from oracle import loop_parity as LP
+    final_o, stack_o, trace = LP.oracle_trajectory(orc, vol, used, x_T, 7)
+    assert len(trace) == steps and stack_o.shape[0] == steps + 1
+    bar = max(LP.BAR_FRAC, 1.0 / stack_o[0].numel())
+    for s in LP.teacher_forced(m, trace, dev(vol), dev(used), used, used) + LP.decision_forced(m, trace, dev(vol), dev(used), x_T, used):
+        assert s["frac_gt_1e-3"] <= bar and s["epe_delta"] < LP.BAR_EPE, s
     with torch.no_grad():
         fh, sh = m.ddim_sample(dev(vol), dev(used), dev(x_T), noise=NoiseTape(7))
-    assert sh.shape[0] == steps + 1 == s64.shape[0]
-    e_h, e_o = (sh.cpu().double() - s64).abs(), (s32.double() - s64).abs()
-    for i in (1, 2):
-        assert float(e_h[i].mean()) < 3 * float(e_o[i].mean()) + 5e-5, (i, float(e_h[i].mean()), float(e_o[i].mean()))
-    for i in range(1, steps + 1):
-        assert float(e_h[i].median()) < 5e-4, (i, float(e_h[i].median()))
-    assert float((fh.cpu().double() - f64).abs().median()) < 5e-4
+    assert sh.shape[0] == steps + 1
+    assert float((sh[1].cpu() - stack_o[1]).abs().max()) < 2e-3          # before any decision is fed back
 
 
 # ---------------------------------------------------------------- 2-D Winograd kernel (csrc/conv2d_wino.hip)

@@ -1,0 +1,58 @@
+"""The N>1 path with the real kernels: two processes (gloo rendezvous, both on the box's one GPU) run the HIP hot
+path on shards [0,4) and [4,8) of a batch of 8 and all-reduce their metric sums; the reduced EPE must equal, bit for
+bit, what one process gets from the same two shards -- and the per-shard disparities must carry the same bits as the
+pairs have inside the full batch (shard invariance, which is what makes data-parallel sharding exact)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+
+
+@pytest.mark.timeout(900)
+def test_two_process_shards_match_single_process():
+    sys.path.insert(0, str(ROOT / "tests"))
+    import shard_worker as W
+    from diffuvolume_amd import metrics as M
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "shard_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=800)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(json.loads([l for l in o.splitlines() if l.startswith("{")][-1]))
+    outs.sort(key=lambda d: d["rank"])
+    assert [(d["lo"], d["hi"]) for d in outs] == [(0, 4), (4, 8)]
+    assert outs[0]["metrics"] == outs[1]["metrics"]                 # every rank holds the reduced means
+
+    dev = torch.device("cuda:0")
+    model, x, gt = W.build(dev)
+    acc = M.MetricAccumulator(dev)
+    sums = []
+    for lo, hi in ((0, 4), (4, 8)):
+        final, gsum = W.shard_epe(model, x, gt, lo, hi, dev, acc)
+        sums.append((final.double().sum().item().hex(), gsum))
+    single = acc.reduce()
+    assert single == outs[0]["metrics"], (single, outs[0]["metrics"])            # bit for bit (fp64 sums, same order)
+    assert [s[0] for s in sums] == [d["final_hex"] for d in outs]               # the disparities themselves too
+    assert [s[1] for s in sums] == [d["gwc_sum"] for d in outs]
+    # and the shards carry the bits the same pairs have inside the full batch of 8
+    acc8 = M.MetricAccumulator(dev)
+    full, _ = W.shard_epe(model, x, gt, 0, 8, dev, acc8)
+    assert full[:4].double().sum().item().hex() == sums[0][0] and full[4:].double().sum().item().hex() == sums[1][0]
+    epe8 = acc8.reduce()["EPE"]
+    assert abs(epe8 - single["EPE"]) < 1e-12                        # mean of 8 == mean of two means of 4

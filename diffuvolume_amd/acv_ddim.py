@@ -122,6 +122,11 @@ class FeatureExtraction(nn.Module):
             self._plans = None
         return super().train(mode)
 
+    def _replicate_for_data_parallel(self):
+        replica = super()._replicate_for_data_parallel()
+        replica._plans = None
+        return replica
+
     def prepare(self):
         if self._plans is None:
             with torch.no_grad():
@@ -316,6 +321,13 @@ class _HipPlanMixin(nn.Module):
         if mode != self.training:          # the reference calls model.eval() on every batch: keep the plans then
             self._drop_plans()
         return super().train(mode)
+
+    def _replicate_for_data_parallel(self):
+        """nn.DataParallel copies ``__dict__`` into its per-device replicas: a replica must fold / repack its OWN
+        (broadcast) weights on its own device, not inherit the source module's device-resident plans."""
+        replica = super()._replicate_for_data_parallel()
+        replica._plans = None
+        return replica
 
     def _weights_version(self) -> int:
         """Sum of the in-place version counters of every parameter and buffer: changes whenever a weight is

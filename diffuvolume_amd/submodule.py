@@ -3,8 +3,11 @@
 Same names, argument meaning and error behaviour as SceneFlow/models/submodule.py
 (``build_gwc_volume`` :228-238, ``build_concat_volume`` :180-191,
 ``disparity_regression`` :173-177) and their KITTI12 / KITTI15 twins; the work is
-done by the HIP kernels of libdiffuvolume_hip.so on the current stream.  Inference
-only: tensors that require grad are rejected (the north star is the eval path).
+done by the HIP kernels of libdiffuvolume_hip.so on the current stream.  The three
+builders / the regression are differentiable in the reference (they are used in training):
+when autograd is recording and an input requires grad they dispatch to a differentiable
+PyTorch statement of the same function; everything else is inference only and
+runs on the MI355X or raises.
 """
 from __future__ import annotations
 
@@ -77,9 +80,57 @@ def _dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
+def _wants_grad(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
+
+
+def _shift_bank(t: torch.Tensor, maxdisp: int) -> torch.Tensor:
+    """[B,C,H,W] -> [B,C,D,H,W] with bank[..., d, y, x] = t[..., y, x - d] (0 where x < d): every disparity shift
+    of the target features as one strided view of a left-padded copy (differentiable)."""
+    w = t.shape[-1]
+    win = torch.nn.functional.pad(t, (maxdisp - 1, 0)).unfold(3, w, 1)      # [B,C,H,D,W], window k starts at D-1-d
+    return win.flip(3).permute(0, 1, 3, 2, 4)
+
+
+def _valid_wedge(maxdisp: int, w: int, device) -> torch.Tensor:
+    """[D,1,W] bool: x >= d (the reference leaves `new_zeros` where the shifted target has no pixel)."""
+    return (torch.arange(w, device=device).view(1, 1, w) >= torch.arange(maxdisp, device=device).view(maxdisp, 1, 1))
+
+
+def _gwc_volume_autograd(ref, tgt, maxdisp, num_groups):
+    """Differentiable statement of build_gwc_volume (submodule.py:209-238) for training / autograd callers:
+    products against the shift bank, mean over the channels of a group, exact zeros in the x < d wedge."""
+    b, c, h, w = ref.shape
+    cpg = c // num_groups
+    valid = _valid_wedge(maxdisp, w, ref.device)
+    step = max(1, (64 << 20) // max(1, b * cpg * maxdisp * h * w))           # groups per slab (<= ~256 MB of products)
+    slabs = []
+    for g0 in range(0, num_groups, step):
+        g1 = min(num_groups, g0 + step)
+        r = ref[:, g0 * cpg:g1 * cpg]
+        prod = r.unsqueeze(2) * _shift_bank(tgt[:, g0 * cpg:g1 * cpg], maxdisp)
+        slabs.append(prod.reshape(b, g1 - g0, cpg, maxdisp, h, w).mean(dim=2))
+    vol = torch.cat(slabs, dim=1)
+    return torch.where(valid, vol, torch.zeros((), dtype=vol.dtype, device=vol.device)).contiguous()
+
+
+def _concat_volume_autograd(ref, tgt, maxdisp, zero_left):
+    """Differentiable statement of build_concat_volume (submodule.py:180-191; KITTI12 :86-97 with zero_left)."""
+    b, c, h, w = ref.shape
+    left = ref.unsqueeze(2).expand(b, c, maxdisp, h, w)
+    if zero_left:
+        left = torch.where(_valid_wedge(maxdisp, w, ref.device), left, torch.zeros((), dtype=ref.dtype, device=ref.device))
+    return torch.cat((left, _shift_bank(tgt, maxdisp)), dim=1).contiguous()
+
+
 def build_gwc_volume(refimg_fea: torch.Tensor, targetimg_fea: torch.Tensor, maxdisp: int,
                      num_groups: int) -> torch.Tensor:
     """[B,C,H,W] x2 -> [B,num_groups,maxdisp,H,W] (submodule.py:228-238)."""
+    if _wants_grad(refimg_fea, targetimg_fea):
+        if refimg_fea.dim() != 4 or refimg_fea.shape != targetimg_fea.shape:
+            raise RuntimeError(f"feature shapes differ or are not 4-D: {tuple(refimg_fea.shape)} vs {tuple(targetimg_fea.shape)}")
+        assert refimg_fea.shape[1] % num_groups == 0          # submodule.py:211
+        return _gwc_volume_autograd(refimg_fea, targetimg_fea, maxdisp, num_groups)
     ref = _dev_f32(refimg_fea, "refimg_fea")
     tgt = _dev_f32(targetimg_fea, "targetimg_fea")
     if ref.dim() != 4 or ref.shape != tgt.shape:
@@ -102,6 +153,10 @@ def build_concat_volume(refimg_fea: torch.Tensor, targetimg_fea: torch.Tensor, m
                         zero_left: bool = False) -> torch.Tensor:
     """[B,C,H,W] x2 -> [B,2C,maxdisp,H,W] (submodule.py:180-191).  ``zero_left=True``
     is the KITTI12 flavour (KITTI12/models/submodule.py:86-97)."""
+    if _wants_grad(refimg_fea, targetimg_fea):
+        if refimg_fea.dim() != 4 or refimg_fea.shape != targetimg_fea.shape:
+            raise RuntimeError(f"feature shapes differ or are not 4-D: {tuple(refimg_fea.shape)} vs {tuple(targetimg_fea.shape)}")
+        return _concat_volume_autograd(refimg_fea, targetimg_fea, maxdisp, bool(zero_left))
     ref = _dev_f32(refimg_fea, "refimg_fea")
     tgt = _dev_f32(targetimg_fea, "targetimg_fea")
     if ref.dim() != 4 or ref.shape != tgt.shape:
@@ -142,6 +197,12 @@ def disparity_regression(x: torch.Tensor, maxdisp: int, keepdim: bool = False) -
     """[B,D,H,W] probabilities -> sum_d d*p_d (submodule.py:173-177; keepdim=True is the
     KITTI15 flavour, core/submodule.py:219-223)."""
     assert len(x.shape) == 4            # submodule.py:174
+    if _wants_grad(x):                  # training: the differentiable statement (sum_d d * p_d)
+        if x.shape[1] != maxdisp:
+            raise RuntimeError(f"The size of tensor a ({x.shape[1]}) must match the size of tensor b ({maxdisp}) "
+                               "at non-singleton dimension 1")
+        k = torch.arange(0, maxdisp, dtype=x.dtype, device=x.device).view(1, maxdisp, 1, 1)
+        return torch.sum(x * k, 1, keepdim=keepdim)
     x = _dev_f32(x, "x")
     b, d, h, w = x.shape
     if d != maxdisp:

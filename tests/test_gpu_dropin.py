@@ -1,0 +1,93 @@
+"""Call-site compatibility of the drop-in modules (SceneFlow/test_sceneflow_ddim.py:54-61, :100-108): the reference
+wraps the model in nn.DataParallel, loads the checkpoint THROUGH the wrapper and calls model.eval() on every batch."""
+import pytest
+import torch
+from torch import nn
+
+import diffuvolume_amd as dv
+from diffuvolume_amd.synth import synth_state_dict, synth_stereo_batch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model(seed):
+    m = dv.ACVNet_DDIM(192, False, False)
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed=seed, logit_gain=8.0), strict=True)
+    return m.to(DEV).eval()
+
+
+def _run(model, batch):
+    torch.cuda.manual_seed(1234)            # forward() draws the DDIM noise from the device generator
+    with torch.no_grad():
+        return model(batch["left"], batch["right"], batch["used"], batch["disp"], None)[0]
+
+
+@pytest.fixture(scope="module")
+def batch():
+    return {k: v.to(DEV) for k, v in synth_stereo_batch(2, 64, 128, seed=3, shifts=(8, 20)).items()}
+
+
+def test_data_parallel_single_device_same_bits(batch):
+    bare = _model(1)
+    ref = _run(bare, batch)
+    wrapped = nn.DataParallel(bare, device_ids=[0])
+    wrapped.eval()
+    assert torch.equal(_run(wrapped, batch), ref)
+    assert bare._plans is not None
+    plans = bare._plans
+    wrapped.eval()                           # the reference does this before every batch: plans must survive it
+    assert bare._plans is plans
+
+
+def test_checkpoint_loaded_through_the_wrapper_rebuilds_the_plans(batch):
+    model = _model(1)
+    wrapped = nn.DataParallel(model, device_ids=[0])
+    first = _run(wrapped, batch)
+    sd2 = {"module." + k: v for k, v in synth_state_dict(model.state_dict(), seed=2, logit_gain=8.0).items()}
+    wrapped.load_state_dict(sd2)             # nn.DataParallel(model).load_state_dict(...), test_sceneflow_ddim.py:59-61
+    second = _run(wrapped, batch)
+    assert not torch.equal(first, second)
+    assert torch.equal(second, _run(_model(2), batch))
+    # weights overwritten in place behind the module's back (no hook fires) are noticed at the next call too
+    with torch.no_grad():
+        for k, v in synth_state_dict(model.state_dict(), seed=1, logit_gain=8.0).items():
+            model.state_dict()[k].copy_(v)
+    assert torch.equal(_run(wrapped, batch), first)
+
+
+def test_data_parallel_replicas_build_their_own_plans(batch):
+    """device_ids=[0,0]: two replicas (threads) on the one GPU of the box -- the replica path of a multi-GPU
+    DataParallel, and two concurrent callers of the C ABI."""
+    bare = _model(1)
+    halves = [_run(bare, {k: v[i:i + 1] for k, v in batch.items()}) for i in range(2)]
+    try:
+        wrapped = nn.DataParallel(bare, device_ids=[0, 0])
+        torch.cuda.manual_seed(1234)
+        with torch.no_grad():
+            out = wrapped(batch["left"], batch["right"], batch["used"], batch["disp"])
+    except (RuntimeError, AssertionError) as e:
+        if "plan" in str(e).lower() or "diffuvolume" in str(e).lower():
+            raise
+        pytest.skip(f"this torch build does not take duplicate device ids: {e}")
+    out = out[0] if isinstance(out, (list, tuple)) else out
+    assert out.shape == (2,) + tuple(halves[0].shape[1:])
+    assert bool(torch.isfinite(out).all())
+    # the replicas draw their noise in thread order, so compare what does not depend on the draws: step-1 agreement
+    # is covered elsewhere; here the outputs must be finite, the right shape and on the right device
+    assert out.device == torch.device(DEV)
+
+
+def test_mis_sized_used_is_an_error_not_an_out_of_bounds_access(batch):
+    model = _model(1)
+    with torch.no_grad():
+        fl = model.feature_extraction(batch["left"])["gwc_feature"]
+        fr = model.feature_extraction(batch["right"])["gwc_feature"]
+        vol = model.attention_concat_volume(fl, fr)
+        x_T = model.encode_disparity(batch["disp"])
+    with pytest.raises(RuntimeError, match="must match"):
+        model.ddim_sample(vol, batch["used"][:, :-4], x_T)                    # an uncropped / differently padded image
+    with pytest.raises(RuntimeError, match="must match"):
+        model.ddim_sample(vol, batch["used"][:, ::4, ::4].contiguous(), x_T)
+    with pytest.raises(RuntimeError):
+        model.ddim_sample(vol, batch["used"], x_T[:, :24])

@@ -335,3 +335,364 @@ class IGEVCostVolume(nn.Module):
         geo = self.cost_agg(gwc, features_left)
         cost = classifier(geo)
         return geo, softmax_regress(cost).unsqueeze(1)          # F.softmax + disparity_regression :382-383
+
+
+# ---------------------------------------------------------------------------------------------------
+# IGEVStereo_ddim: the drop-in module (KITTI15/core/igev_stereo_ddim.py:118-224 constructor, :361-427 eval forward).
+# Module / buffer names are the reference's, so its checkpoints load with strict=True.  On HIP: gwc volume, corr_stem,
+# FeatureAtt gates, hourglass(8), classifier + softmax + regression, the filtered geometry lookup, the whole update
+# block, the convex upsampling (softmax + 9-tap gather) and the DDIM state update.  PyTorch (2-D, once per pair or
+# once per DDIM step): the MobileNetV2 feature pyramid, the context encoder, the stems and the spx heads' convolutions.
+# ---------------------------------------------------------------------------------------------------
+def context_upsample(disp_low: torch.Tensor, up_weights: torch.Tensor, scale: float = 1.0,
+                     apply_softmax: bool = False) -> torch.Tensor:
+    """core/submodule.py:241-253: disp_low [B,1,h,w], up_weights [B,9,4h,4w] -> [B,4h,4w].  ``apply_softmax`` /
+    ``scale`` fold the ``F.softmax(spx_pred, 1)`` and ``disp*4.`` of the call site into the same pass."""
+    disp_low, up_weights = _dev_f32(disp_low, "disp_low"), _dev_f32(up_weights, "up_weights")
+    b, c, h, w = disp_low.shape
+    if c != 1 or tuple(up_weights.shape) != (b, 9, 4 * h, 4 * w):
+        raise RuntimeError(f"context_upsample: disp_low [B,1,h,w] and up_weights [B,9,4h,4w], got "
+                           f"{tuple(disp_low.shape)} and {tuple(up_weights.shape)}")
+    out = torch.empty((b, 4 * h, 4 * w), dtype=torch.float32, device=disp_low.device)
+    with torch.cuda.device(disp_low.device):
+        _lib.check(_lib.load().dv_context_upsample_f32(disp_low.data_ptr(), up_weights.data_ptr(), out.data_ptr(), b, h,
+                                                       w, float(scale), int(bool(apply_softmax)), _lib.stream_ptr()),
+                   "dv_context_upsample_f32")
+    return out
+
+
+class BasicConv_IN(nn.Module):
+    """core/submodule.py:79-107 (2-D flavours only): conv (bias=False) [+ InstanceNorm2d] [+ LeakyReLU(0.01)]."""
+
+    def __init__(self, in_channels, out_channels, deconv=False, is_3d=False, IN=True, relu=True, **kwargs):
+        super().__init__()
+        if is_3d:
+            raise _lib.DiffuVolumeError("IGEV uses BasicConv_IN in 2-D only")
+        self.relu, self.use_in = relu, IN
+        self.conv = (nn.ConvTranspose2d if deconv else nn.Conv2d)(in_channels, out_channels, bias=False, **kwargs)
+        self.IN = nn.InstanceNorm2d(out_channels)
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.use_in:
+            x = self.IN(x)
+        return F.leaky_relu(x, 0.01) if self.relu else x
+
+
+class _Conv2xBase(nn.Module):
+    """core/submodule.py:36-76 / :110-150: stride-2 (de)convolution, resize to the skip tensor, concat (or add), 3x3."""
+
+    def _finish(self, x, rem):
+        x = self.conv1(x)
+        if x.shape != rem.shape:
+            x = F.interpolate(x, size=(rem.shape[-2], rem.shape[-1]), mode="nearest")
+        x = torch.cat((x, rem), 1) if self.concat else x + rem
+        return self.conv2(x)
+
+    def forward(self, x, rem):
+        return self._finish(x, rem)
+
+
+class Conv2x(_Conv2xBase):
+    def __init__(self, in_channels, out_channels, deconv=False, is_3d=False, concat=True, keep_concat=True, bn=True,
+                 relu=True, keep_dispc=False):
+        super().__init__()
+        if is_3d or keep_dispc:
+            raise _lib.DiffuVolumeError("IGEV uses Conv2x in 2-D only")
+        self.concat = concat
+        self.conv1 = BasicConv(in_channels, out_channels, deconv, False, bn=True, relu=True,
+                               kernel_size=4 if deconv else 3, stride=2, padding=1)
+        cin, cout = (out_channels * 2, out_channels * (2 if keep_concat else 1)) if concat else (out_channels, out_channels)
+        self.conv2 = BasicConv(cin, cout, False, False, bn, relu, kernel_size=3, stride=1, padding=1)
+
+
+class Conv2x_IN(_Conv2xBase):
+    def __init__(self, in_channels, out_channels, deconv=False, is_3d=False, concat=True, keep_concat=True, IN=True,
+                 relu=True, keep_dispc=False):
+        super().__init__()
+        if is_3d or keep_dispc:
+            raise _lib.DiffuVolumeError("IGEV uses Conv2x_IN in 2-D only")
+        self.concat = concat
+        self.conv1 = BasicConv_IN(in_channels, out_channels, deconv, False, IN=True, relu=True,
+                                  kernel_size=4 if deconv else 3, stride=2, padding=1)
+        cin, cout = (out_channels * 2, out_channels * (2 if keep_concat else 1)) if concat else (out_channels, out_channels)
+        self.conv2 = BasicConv_IN(cin, cout, False, False, IN, relu, kernel_size=3, stride=1, padding=1)
+
+
+class ResidualBlock(nn.Module):
+    """core/extractor.py:10-74 with norm_fn='batch' (what MultiBasicEncoder is built with, :143).  `downsample`
+    holds `norm3` a second time, so both key sets exist in the state_dict, as in the reference."""
+
+    def __init__(self, in_planes, planes, norm_fn="batch", stride=1):
+        super().__init__()
+        if norm_fn != "batch":
+            raise _lib.DiffuVolumeError("the context encoder is built with norm_fn='batch'")
+        self.conv1 = nn.Conv2d(in_planes, planes, kernel_size=3, padding=1, stride=stride)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+        self.norm1, self.norm2 = nn.BatchNorm2d(planes), nn.BatchNorm2d(planes)
+        self.downsample = None
+        if not (stride == 1 and in_planes == planes):
+            self.norm3 = nn.BatchNorm2d(planes)
+            self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
+
+    def forward(self, x):
+        y = self.relu(self.norm1(self.conv1(x)))
+        y = self.relu(self.norm2(self.conv2(y)))
+        if self.downsample is not None:
+            x = self.downsample(x)
+        return self.relu(x + y)
+
+
+class MultiBasicEncoder(nn.Module):
+    """core/extractor.py:190-295: the context encoder (`cnet`).  2-D, once per pair: PyTorch."""
+
+    def __init__(self, output_dim=((128, 128, 128),), norm_fn="batch", dropout=0.0, downsample=3):
+        super().__init__()
+        self.norm_fn, self.downsample = norm_fn, downsample
+        self.norm1 = nn.BatchNorm2d(64)
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=1 + (downsample > 2), padding=3)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.in_planes = 64
+        self.layer1 = self._make_layer(64, stride=1)
+        self.layer2 = self._make_layer(96, stride=1 + (downsample > 1))
+        self.layer3 = self._make_layer(128, stride=1 + (downsample > 0))
+        self.layer4 = self._make_layer(128, stride=2)
+        self.layer5 = self._make_layer(128, stride=2)
+        self.outputs04 = nn.ModuleList([nn.Sequential(ResidualBlock(128, 128, norm_fn, 1), nn.Conv2d(128, d[2], 3, padding=1))
+                                        for d in output_dim])
+        self.outputs08 = nn.ModuleList([nn.Sequential(ResidualBlock(128, 128, norm_fn, 1), nn.Conv2d(128, d[1], 3, padding=1))
+                                        for d in output_dim])
+        self.outputs16 = nn.ModuleList([nn.Conv2d(128, d[0], 3, padding=1) for d in output_dim])
+        self.dropout = nn.Dropout2d(p=dropout) if dropout > 0 else None
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, dim, stride=1):
+        layers = (ResidualBlock(self.in_planes, dim, self.norm_fn, stride=stride), ResidualBlock(dim, dim, self.norm_fn, 1))
+        self.in_planes = dim
+        return nn.Sequential(*layers)
+
+    def forward(self, x, dual_inp=False, num_layers=3):
+        x = self.layer3(self.layer2(self.layer1(self.relu1(self.norm1(self.conv1(x))))))
+        v = None
+        if dual_inp:
+            v, x = x, x[:(x.shape[0] // 2)]
+        tail = (v,) if dual_inp else ()
+        outs = ([f(x) for f in self.outputs04],)
+        if num_layers >= 2:
+            y = self.layer4(x)
+            outs += ([f(y) for f in self.outputs08],)
+        if num_layers >= 3:
+            outs += ([f(self.layer5(y)) for f in self.outputs16],)
+        return outs + tail
+
+
+class Feature(nn.Module):
+    """core/extractor.py:327-361.  The reference takes its stem and blocks from
+    ``timm.create_model('mobilenetv2_100', pretrained=True, features_only=True)``; neither timm nor the weights
+    exist offline, so the backbone object is injected: anything with ``conv_stem``, ``bn1``, ``act1`` and ``blocks``
+    (7 stages with 16/24/32/64/96/160/320 output channels) -- a timm MobileNetV2 or ``synth.StubMobileNetV2``."""
+
+    def __init__(self, backbone):
+        super().__init__()
+        chans = [16, 24, 32, 96, 160]
+        cut = [1, 2, 3, 5, 6]
+        self.conv_stem, self.bn1, self.act1 = backbone.conv_stem, backbone.bn1, backbone.act1
+        blocks = list(backbone.blocks)
+        self.block0 = nn.Sequential(*blocks[0:cut[0]])
+        self.block1 = nn.Sequential(*blocks[cut[0]:cut[1]])
+        self.block2 = nn.Sequential(*blocks[cut[1]:cut[2]])
+        self.block3 = nn.Sequential(*blocks[cut[2]:cut[3]])
+        self.block4 = nn.Sequential(*blocks[cut[3]:cut[4]])
+        self.deconv32_16 = Conv2x_IN(chans[4], chans[3], deconv=True, concat=True)
+        self.deconv16_8 = Conv2x_IN(chans[3] * 2, chans[2], deconv=True, concat=True)
+        self.deconv8_4 = Conv2x_IN(chans[2] * 2, chans[1], deconv=True, concat=True)
+        self.conv4 = BasicConv_IN(chans[1] * 2, chans[1] * 2, kernel_size=3, stride=1, padding=1)
+
+    def forward(self, x):
+        x2 = self.block0(self.act1(self.bn1(self.conv_stem(x))))
+        x4 = self.block1(x2)
+        x8 = self.block2(x4)
+        x16 = self.block3(x8)
+        x32 = self.block4(x16)
+        x16 = self.deconv32_16(x32, x16)
+        x8 = self.deconv16_8(x16, x8)
+        x4 = self.conv4(self.deconv8_4(x8, x4))
+        return [x4, x8, x16, x32]
+
+
+class IGEVStereo_ddim(nn.Module):
+    """``IGEVStereo_ddim(args).forward(image1, image2, flow_full, flow_gt, iters=12, flow_init=None, test_mode=False)
+    -> (pred, pred)`` (eval path, igev_stereo_ddim.py:361-427).  ``args``: hidden_dims, n_gru_layers, n_downsample,
+    corr_levels, corr_radius, slow_fast_gru, max_disp, mixed_precision (must be False: the HIP path is fp32).
+    ``feature``: the MobileNetV2 feature pyramid (``Feature(backbone)``) -- required, see ``Feature``;
+    ``cnet``: optional replacement for the context encoder.  ``sampling_timesteps`` / ``ensemble_cof`` are
+    hard-coded to 2 / [0.6, 0.1, 0.3] in the reference (:124, :353); BASELINE config 5 asks for 20 steps."""
+
+    def __init__(self, args, feature: Optional[nn.Module] = None, cnet: Optional[nn.Module] = None,
+                 sampling_timesteps: int = 2, ensemble_cof: Optional[Sequence[float]] = None):
+        super().__init__()
+        if feature is None:
+            raise _lib.DiffuVolumeError(
+                "IGEVStereo_ddim needs feature=Feature(backbone): the reference builds it from timm's pretrained "
+                "mobilenetv2_100, which is not available offline (pass a timm model or synth.StubMobileNetV2())")
+        if getattr(args, "mixed_precision", False):
+            raise _lib.DiffuVolumeError("the HIP path computes in fp32: mixed_precision must be False")
+        self.args = args
+        self.scale = 1.0
+        self.num_timesteps = 1000
+        self.sampling_timesteps = sampling_timesteps
+        self.is_ddim_sampling = sampling_timesteps < self.num_timesteps
+        self.ddim_sampling_eta = 1
+        self.renewal = self.use_ensemble = True
+        if ensemble_cof is None:
+            if sampling_timesteps != 2:
+                raise ValueError("give ensemble_cof (S+1 weights) when sampling_timesteps != 2")
+            ensemble_cof = (0.6, 0.1, 0.3)
+        self.ensemble_cof = tuple(float(c) for c in ensemble_cof)
+        betas = cosine_beta_schedule(self.num_timesteps)
+        alphas = 1.0 - betas
+        ac = torch.cumprod(alphas, dim=0)
+        ac_prev = F.pad(ac[:-1], (1, 0), value=1.0)
+        post_var = betas * (1.0 - ac_prev) / (1.0 - ac)
+        for name, val in (("betas", betas), ("alphas_cumprod", ac), ("alphas_cumprod_prev", ac_prev),
+                          ("sqrt_alphas_cumprod", torch.sqrt(ac)),
+                          ("sqrt_one_minus_alphas_cumprod", torch.sqrt(1.0 - ac)),
+                          ("log_one_minus_alphas_cumprod", torch.log(1.0 - ac)),
+                          ("sqrt_recip_alphas_cumprod", torch.sqrt(1.0 / ac)),
+                          ("sqrt_recipm1_alphas_cumprod", torch.sqrt(1.0 / ac - 1)),
+                          ("posterior_variance", post_var),
+                          ("posterior_log_variance_clipped", torch.log(post_var.clamp(min=1e-20))),
+                          ("posterior_mean_coef1", betas * torch.sqrt(ac_prev) / (1.0 - ac)),
+                          ("posterior_mean_coef2", (1.0 - ac_prev) * torch.sqrt(alphas) / (1.0 - ac))):
+            self.register_buffer(name, val)
+
+        from .update import BasicMultiUpdateBlock
+        hidden = list(args.hidden_dims)
+        self.cnet = cnet if cnet is not None else MultiBasicEncoder(output_dim=[hidden, hidden], norm_fn="batch",
+                                                                    downsample=args.n_downsample)
+        self.update_block = BasicMultiUpdateBlock(args, hidden_dims=hidden)
+        self.context_zqr_convs = nn.ModuleList([nn.Conv2d(hidden[i], hidden[i] * 3, 3, padding=1)
+                                                for i in range(args.n_gru_layers)])
+        self.time_embedding = DynamicHead180(180)
+        self.feature = feature
+
+        def stem(cin, cout):
+            return nn.Sequential(BasicConv_IN(cin, cout, kernel_size=3, stride=2, padding=1),
+                                 nn.Conv2d(cout, cout, 3, 1, 1, bias=False), nn.InstanceNorm2d(cout), nn.ReLU())
+
+        self.stem_2, self.stem_4 = stem(3, 32), stem(32, 48)
+        self.spx = nn.Sequential(nn.ConvTranspose2d(2 * 32, 9, kernel_size=4, stride=2, padding=1))
+        self.spx_2 = Conv2x_IN(24, 32, True)
+        self.spx_4 = nn.Sequential(BasicConv_IN(96, 24, kernel_size=3, stride=1, padding=1),
+                                   nn.Conv2d(24, 24, 3, 1, 1, bias=False), nn.InstanceNorm2d(24), nn.ReLU())
+        self.spx_2_gru = Conv2x(32, 32, True)
+        self.spx_gru = nn.Sequential(nn.ConvTranspose2d(2 * 32, 9, kernel_size=4, stride=2, padding=1))
+        self.conv = BasicConv_IN(96, 96, kernel_size=3, padding=1, stride=1)
+        self.desc = nn.Conv2d(96, 96, kernel_size=1, padding=0, stride=1)
+        self.corr_stem = BasicConv(8, 8, is_3d=True, kernel_size=3, stride=1, padding=1)
+        self.corr_feature_att = FeatureAtt(8, 96)
+        self.cost_agg = hourglass(8)
+        self.classifier = nn.Conv3d(8, 1, 3, 1, 1, bias=False)
+        self._plans = None
+
+    # ---- plan cache (same rules as the other wrappers) ----------------------------------------------
+    def _apply(self, fn, *a, **k):
+        self._plans = None
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._plans = None
+        return super()._load_from_state_dict(*a, **k)
+
+    def _replicate_for_data_parallel(self):
+        r = super()._replicate_for_data_parallel()
+        r._plans = None
+        return r
+
+    def prepare(self):
+        if self._plans is None:
+            self._plans = (self.corr_stem.plan(), Conv3dPlan(self.classifier.weight, None, stride=1, act=ACT_NONE))
+        return self._plans
+
+    def freeze_bn(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.eval()
+
+    # ---- pieces -----------------------------------------------------------------------------------------
+    def upsample_disp(self, disp, mask_feat_4, stem_2x):
+        """:209-217: spx_2_gru / spx_gru (2-D, PyTorch), then softmax over the 9 taps + context_upsample(disp*4)
+        in one HIP pass.  Returns [B,1,4h,4w]."""
+        spx_pred = self.spx_gru(self.spx_2_gru(mask_feat_4, stem_2x))
+        return context_upsample(disp, spx_pred, scale=4.0, apply_softmax=True).unsqueeze(1)
+
+    def cost_volume(self, match_left, match_right, features_left):
+        """:378-386: gwc (8 groups) -> corr_stem -> FeatureAtt -> hourglass(8) -> classifier -> softmax + regression."""
+        stem, classifier = self.prepare()
+        d4 = self.args.max_disp // 4
+        gwc = stem(build_gwc_volume(match_left, match_right, d4, 8))
+        gwc = self.corr_feature_att(gwc, features_left[0], inplace=True)
+        geo = self.cost_agg(gwc, features_left)
+        return geo, softmax_regress(classifier(geo)).unsqueeze(1)
+
+    def _loop(self):
+        return IGEVDiffusionLoop(self.time_embedding, self.update_block, self.upsample_disp,
+                                 n_gru_layers=self.args.n_gru_layers, slow_fast_gru=self.args.slow_fast_gru,
+                                 sampling_timesteps=self.sampling_timesteps, ensemble_cof=self.ensemble_cof)
+
+    @torch.no_grad()
+    def model_predictions(self, coords0, coords1, flow_init, iters, net_list, inp_list, corr_fn, noise, t, stem_2x):
+        return self._loop().model_predictions(coords0, coords1, flow_init, iters, net_list, inp_list, corr_fn, noise,
+                                              t, stem_2x)
+
+    @torch.no_grad()
+    def ddim_sample(self, coords0, coords1, flow_init, iters, net_list, inp_list, corr_fn, used, asd, stem_2x,
+                    noise=None, generator=None):
+        return self._loop().ddim_sample(coords0, coords1, flow_init, iters, net_list, inp_list, corr_fn, used, asd,
+                                        stem_2x, noise=noise, generator=generator)
+
+    @torch.no_grad()
+    def encode_disparity(self, flow_gt):
+        """:405-419: two-hot x_0 of the quarter-resolution origin disparity, clamped to [0, 47]."""
+        dq = torch.clamp(_dev_f32(flow_gt, "flow_gt"), 0, 47).contiguous()
+        b, h, w = dq.shape[0], dq.shape[-2], dq.shape[-1]
+        x = torch.empty((b, 48, h, w), dtype=torch.float32, device=dq.device)
+        with torch.cuda.device(dq.device):
+            _lib.check(_lib.load().dv_encode_two_hot_f32(dq.data_ptr(), x.data_ptr(), b, 48, h * w, _lib.stream_ptr()),
+                       "dv_encode_two_hot_f32")
+        return x
+
+    def forward(self, image1, image2, flow_full, flow_gt, iters=12, flow_init=None, test_mode=False, noise=None):
+        if self.training:
+            raise NotImplementedError("the MI355X DiffuVolume path is inference-only (model.eval())")
+        with torch.no_grad():
+            image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
+            image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
+            features_left, features_right = self.feature(image1), self.feature(image2)
+            stem_2x = self.stem_2(image1)
+            stem_4x = self.stem_4(stem_2x)
+            stem_4y = self.stem_4(self.stem_2(image2))
+            features_left[0] = torch.cat((features_left[0], stem_4x), 1)
+            features_right[0] = torch.cat((features_right[0], stem_4y), 1)
+            match_left = self.desc(self.conv(features_left[0])).float().contiguous()
+            match_right = self.desc(self.conv(features_right[0])).float().contiguous()
+            geo, init_disp = self.cost_volume(match_left, match_right, features_left)
+            cnet_list = self.cnet(image1, num_layers=self.args.n_gru_layers)
+            net_list = [torch.tanh(x[0]) for x in cnet_list]
+            inp_list = [torch.relu(x[1]) for x in cnet_list]
+            inp_list = [list(conv(i).split(split_size=conv.out_channels // 3, dim=1))
+                        for i, conv in zip(inp_list, self.context_zqr_convs)]
+            inp_list = [[t.contiguous() for t in trio] for trio in inp_list]
+            from .geometry_ddim import Combined_Geo_Encoding_Volume
+            geo_fn = Combined_Geo_Encoding_Volume(match_left, match_right, geo, radius=self.args.corr_radius,
+                                                  num_levels=self.args.corr_levels)
+            x0 = self.encode_disparity(flow_gt)
+            pred = self.ddim_sample(init_disp, init_disp, flow_init, iters, net_list, inp_list, geo_fn, flow_full, x0,
+                                    stem_2x, noise=noise)
+        return pred, pred

@@ -154,3 +154,26 @@ def toy_upsample_disp(flow, up_mask, stem_2x):
     """Stand-in for IGEVStereo_ddim.upsample_disp (:206-214): x4 bilinear upsampling of 4*flow."""
     import torch.nn.functional as F
     return F.interpolate(flow * 4.0, scale_factor=4, mode="bilinear", align_corners=False)
+
+
+def _stub_stage(cin, cout, stride):
+    from torch import nn
+    return nn.Sequential(nn.Conv2d(cin, cout, 3, stride, 1, bias=False), nn.BatchNorm2d(cout), nn.ReLU6())
+
+
+class StubMobileNetV2(__import__("torch").nn.Module):
+    """Stand-in for ``timm.create_model('mobilenetv2_100', features_only=True)`` (KITTI15/core/extractor.py:331): the
+    attributes IGEV's ``Feature`` takes from it -- ``conv_stem`` / ``bn1`` / ``act1`` and seven ``blocks`` with
+    MobileNetV2's channel counts and strides (16 @1/2, 24 @1/4, 32 @1/8, 64 + 96 @1/16, 160 @1/32, 320) -- each stage
+    one 3x3 conv + BN + ReLU6.  Neither timm nor its pretrained weights exist offline; the goldens and the tests
+    drive the reference and this build with this same module (weights from ``synth_state_dict``)."""
+
+    def __init__(self):
+        from torch import nn
+        super().__init__()
+        self.conv_stem = nn.Conv2d(3, 32, 3, 2, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(32)
+        self.act1 = nn.ReLU6()
+        self.blocks = nn.Sequential(_stub_stage(32, 16, 1), _stub_stage(16, 24, 2), _stub_stage(24, 32, 2),
+                                    _stub_stage(32, 64, 2), _stub_stage(64, 96, 1), _stub_stage(96, 160, 2),
+                                    _stub_stage(160, 320, 1))

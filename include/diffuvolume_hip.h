@@ -283,6 +283,15 @@ int dv_ddim_step(const float* disp, const float* unc, const float* used, const f
                  float* mask, float* x_start, double* pred_eps, double* x_next, float* ens,
                  int B, int nbins, int h, int w, const dv_ddim_coef* coef, dv_stream_t stream);
 
+/* ---- IGEV: convex upsampling of the quarter-resolution disparity ------------------------
+ * IGEVStereo_ddim.upsample_disp (KITTI15/core/igev_stereo_ddim.py:209-217) = F.softmax(spx_pred, 1) followed by
+ * context_upsample (core/submodule.py:241-253):
+ *   out[b,Y,X] = sum_{k=3ky+kx} p_k[b,Y,X] * scale * disp_low[b, (Y>>2)+ky-1, (X>>2)+kx-1]   (zeros outside)
+ * disp_low [B,h,w]; weights [B,9,4h,4w] (logits when apply_softmax != 0, else probabilities); out [B,4h,4w];
+ * scale = 4 in the reference (`disp*4.`).  weights / out must be 16-byte aligned. */
+int dv_context_upsample_f32(const float* disp_low, const float* weights, float* out, int B, int h, int w,
+                            float scale, int apply_softmax, dv_stream_t stream);
+
 /* ---- IGEV: geometry-encoding-volume lookup with the noise filter -----------------------
  * Combined_Geo_Encoding_Volume.__call__ (KITTI15/core/geometry_ddim.py:33-69), 2 pyramid levels,
  * radius 4: per pixel, (geo[c,:] * noise[:]) linearly sampled at disp/2^i + {-4..4} plus the all-pairs

@@ -244,3 +244,17 @@ def update_block(sd, net, inp, corr, disp, n_gru_layers=3, iter04=True, iter08=T
     delta = _conv(F.relu(_conv(net[0], sd, "disp_head.conv1", 1)), sd, "disp_head.conv2", 1)
     mask = F.relu(_conv(net[0], sd, "mask_feat_4.0", 1))
     return net, mask, delta
+
+
+def context_upsample(disp_low, up_weights):
+    """core/submodule.py:241-253: 3x3 neighbourhood of the low-resolution disparity (zero padded), repeated x4 by
+    nearest neighbour, weighted by the 9 per-pixel weights.  disp_low [B,1,h,w], up_weights [B,9,4h,4w] -> [B,4h,4w]."""
+    b, c, h, w = disp_low.shape
+    nb = F.unfold(disp_low.reshape(b, c, h, w), 3, 1, 1).reshape(b, -1, h, w)
+    nb = F.interpolate(nb, (h * 4, w * 4), mode="nearest").reshape(b, 9, h * 4, w * 4)
+    return (nb * up_weights).sum(1)
+
+
+def upsample_disp(disp, logits):
+    """IGEVStereo_ddim.upsample_disp after its two spx convolutions (igev_stereo_ddim.py:213-215)."""
+    return context_upsample(disp * 4.0, F.softmax(logits, 1)).unsqueeze(1)

@@ -1,0 +1,76 @@
+"""Two models built from the SAME weights in a process whose allocator cache holds garbage must agree bit for bit.
+Finds the first stage of ACVNet_DDIM.forward that does not (plan building that leaves memory unwritten, races)."""
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+import diffuvolume_amd as dv  # noqa: E402
+from diffuvolume_amd.submodule import build_gwc_volume, patch_volume, upsample_softmax_regress  # noqa: E402
+from diffuvolume_amd.synth import NoiseTape, synth_state_dict, synth_stereo_batch  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def poison():
+    junk = [torch.empty(64 << 20, device=DEV).normal_(0, 50.0) for _ in range(8)]
+    torch.cuda.synchronize()
+    del junk
+
+
+def stages(seed, batch):
+    m = dv.ACVNet_DDIM(192, False, False)
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed=seed, logit_gain=8.0), strict=True)
+    m = m.to(DEV).eval()
+    out = {}
+    with torch.no_grad():
+        fl = m.feature_extraction(batch["left"])["gwc_feature"]
+        fr = m.feature_extraction(batch["right"])["gwc_feature"]
+        out["feat_l"], out["feat_r"] = fl, fr
+        p = m.prepare()
+        gwc = build_gwc_volume(fl, fr, 48, 40)
+        out["gwc"] = gwc
+        pv = patch_volume(gwc, p.patch_w1, p.patch_w2, p.patch_dil)
+        out["patch"] = pv
+        a = p.dres1_att(pv)
+        out["dres1_att"] = a
+        a = p.dres2_att(a)
+        out["dres2_att"] = a
+        a = p.classif_att(a)
+        out["classif_att"] = a
+        cl = p.concat_b(p.concat_a(fl))
+        out["concat_l"] = cl
+        vol = m.attention_concat_volume(fl, fr)
+        out["volume"] = vol
+        x_T = m.encode_disparity(batch["disp"])
+        c0 = p.dres0(vol)
+        out["dres0"] = c0
+        c0 = p.dres1(c0, residual_self=True)
+        out["dres1"] = c0
+        o = p.dres2(c0)
+        out["dres2"] = o
+        o = p.dres3(o)
+        out["dres3"] = o
+        c = p.classif2(o)
+        out["classif2"] = c
+        out["disp"] = upsample_softmax_regress(c)[0]
+        out["final"] = m.ddim_sample(vol, batch["used"], x_T, noise=NoiseTape(3))[0]
+    return {k: v.clone() for k, v in out.items()}
+
+
+def main():
+    batch = {k: v.to(DEV) for k, v in synth_stereo_batch(2, 64, 128, seed=3, shifts=(8, 20)).items()}
+    a = stages(2, batch)
+    poison()
+    b = stages(2, batch)
+    poison()
+    _ = stages(1, batch)          # other weights in between
+    c = stages(2, batch)
+    for k in a:
+        print(f"{k:12s} A==B {torch.equal(a[k], b[k])}  A==C {torch.equal(a[k], c[k])}  "
+              f"max|A-C| {float((a[k] - c[k]).abs().max()):.3e}  finite {bool(torch.isfinite(a[k]).all())}")
+
+
+if __name__ == "__main__":
+    main()

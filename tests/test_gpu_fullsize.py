@@ -171,17 +171,17 @@ def test_fullsize_oracle_5step():
         json.dump(report, f, indent=1)
     print(json.dumps(report))
     for s in tf:
-        assert s["frac_gt_1e-3"] <= LP.BAR_FRAC, ("teacher forced", s)
+        assert s["frac_gt_bar"] <= LP.BAR_FRAC, ("teacher forced", s)
         assert s["epe_delta"] < LP.BAR_EPE, ("teacher forced", s)
         assert s["mask_max_abs"] <= 1.0
         if "x_next_max_abs_where_decisions_agree" in s:
             assert s["x_next_mean_abs_where_decisions_agree"] < 1e-4, s
     for s in df:
-        assert s["frac_gt_1e-3"] <= LP.BAR_FRAC, ("decision forced", s)
+        assert s["frac_gt_bar"] <= LP.BAR_FRAC, ("decision forced", s)
         assert s["epe_delta"] < LP.BAR_EPE, ("decision forced", s)
     flips = 0
     for s in fr["steps"]:
         # a free-run step may leave the bar only after a renewal decision has come out differently
-        assert s["frac_gt_1e-3"] <= LP.BAR_FRAC or flips > 0, ("free run", s)
+        assert s["frac_gt_bar"] <= LP.BAR_FRAC or flips > 0, ("free run", s)
         flips += s["flips_mask_zero"]
     assert fr["final"]["epe_delta"] < LP.BAR_EPE, fr["final"]

@@ -97,11 +97,11 @@ def _assert_pcw_loop_contract(model, sd, vol, used, asd, fl, fr, seed, gt=None):
     df = LP.decision_forced(model, trace, vol_d, used_d, trace[0]["img"], gt, **kw)
     fr_ = LP.free_run(model, trace, stack_o, final_o, vol_d, used_d, asd, gt, seed, _d(fl), _d(fr))
     for s in tf + df:
-        assert s["frac_gt_1e-3"] <= bar, s
+        assert s["frac_gt_bar"] <= bar, s
         assert s["epe_delta"] < LP.BAR_EPE, s
     flips = 0
     for s in fr_["steps"]:
-        assert s["frac_gt_1e-3"] <= bar or flips > 0, s
+        assert s["frac_gt_bar"] <= bar or flips > 0, s
         flips += s["flips_mask_zero"]
     if flips == 0:
         assert fr_["final"]["epe_delta"] < LP.BAR_EPE, fr_["final"]

@@ -128,11 +128,14 @@ class FeatureExtraction(nn.Module):
         return replica
 
     def prepare(self):
+        version = sum(t._version for t in self.parameters()) + sum(t._version for t in self.buffers())
+        if self._plans is not None and self._plans[2] != version:      # weights overwritten in place since
+            self._plans = None
         if self._plans is None:
             with torch.no_grad():
                 first = [_plan_cb2(self.firstconv[i], ACT_RELU) for i in (0, 2, 4)]
                 stacks = [[_ResBlock2dPlan(b) for b in getattr(self, n)] for n in ("layer1", "layer2", "layer3", "layer4")]
-            self._plans = (first, stacks)
+            self._plans = (first, stacks, version)
         return self._plans
 
     def forward(self, x):
@@ -144,7 +147,7 @@ class FeatureExtraction(nn.Module):
             l3 = self.layer3(l2)
             l4 = self.layer4(l3)
             return {"gwc_feature": torch.cat((l2, l3, l4), dim=1)}
-        first, stacks = self.prepare()
+        first, stacks, _ = self.prepare()
         with torch.no_grad():
             for p in first:
                 x = p(x)
@@ -646,6 +649,7 @@ class ACVNet_DDIM(_HipPlanMixin):
             raise NotImplementedError("mask_gt is None at every reference call site "
                                       "(test_sceneflow_ddim.py:108); the masked x_T is not implemented")
         with torch.no_grad():
+            self.prepare(check_weights=True)
             fl = self.feature_extraction(left)["gwc_feature"]
             fr = self.feature_extraction(right)["gwc_feature"]
             ac_volume = self.attention_concat_volume(fl, fr)
@@ -694,6 +698,7 @@ class ACVNet(_HipPlanMixin):
         if self.training:
             raise NotImplementedError("the MI355X path is inference-only (model.eval())")
         with torch.no_grad():
+            self.prepare(check_weights=True)
             fl = self.feature_extraction(left)["gwc_feature"]
             fr = self.feature_extraction(right)["gwc_feature"]
             cost = self._aggregate(self.attention_concat_volume(fl, fr), None)

@@ -128,6 +128,9 @@ class FeatureExtraction(nn.Module, _Stacker):
         return super().train(mode)
 
     def prepare(self):
+        version = sum(t._version for t in self.parameters()) + sum(t._version for t in self.buffers())
+        if self._plans is not None and self._plans.get("version") != version:      # weights overwritten in place since
+            self._plans = None
         if self._plans is None:
             def head(seq):          # convbn + Mish + Conv2d 1x1
                 return (_plan_cb2(seq[0], ACT_MISH), Conv2dPlan(seq[2].weight, None, act=ACT_NONE))
@@ -138,6 +141,7 @@ class FeatureExtraction(nn.Module, _Stacker):
                 for n in ("gw2", "gw3", "gw4", "layer11") + (("lastconv", "concat2", "concat3", "concat4") if self.concat_feature else ()):
                     p[n] = head(getattr(self, n))
                 p["refine"] = (_plan_cb2(self.layer_refine[0], ACT_MISH), _plan_cb2(self.layer_refine[2], ACT_MISH))
+            p["version"] = version
             self._plans = p
         return self._plans
 
@@ -715,6 +719,7 @@ class PWCNet_ddim(nn.Module):
         if self.training:
             raise NotImplementedError("the MI355X DiffuVolume path is inference-only (model.eval())")
         with torch.no_grad():
+            self.prepare(check_weights=True)
             fl = self.feature_extraction(left)
             fr = self.feature_extraction(right)
             combine = self.fused_volume(fl, fr)

@@ -176,12 +176,11 @@ def test_fullsize_oracle_5step():
         assert s["mask_max_abs"] <= 1.0
         if "x_next_max_abs_where_decisions_agree" in s:
             assert s["x_next_mean_abs_where_decisions_agree"] < 1e-4, s
-    for s in df:
-        assert s["frac_gt_bar"] <= LP.BAR_FRAC, ("decision forced", s)
-        assert s["epe_delta"] < LP.BAR_EPE, ("decision forced", s)
-    flips = 0
-    for s in fr["steps"]:
-        # a free-run step may leave the bar only after a renewal decision has come out differently
-        assert s["frac_gt_bar"] <= LP.BAR_FRAC or flips > 0, ("free run", s)
-        flips += s["flips_mask_zero"]
+    flips = sum(s["flips_mask_zero"] for s in fr["steps"])
+    for s in df + (fr["steps"] if flips == 0 else []):
+        # trajectory level (HIP on its own state): the contract's EPE bar at every step; pixels held to the same
+        # spread-scaled bar -- at this size the step map does not amplify the 1e-4 px state differences beyond it
+        assert s["epe_delta"] < LP.BAR_EPE, s
+        assert s["frac_gt_bar"] <= LP.BAR_FRAC, s
     assert fr["final"]["epe_delta"] < LP.BAR_EPE, fr["final"]
+    assert fr["final"]["frac_gt_1e-3"] <= LP.BAR_FRAC or flips > 0, fr["final"]   # the ensemble output: raw contract bar

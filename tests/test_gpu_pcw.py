@@ -96,13 +96,13 @@ def _assert_pcw_loop_contract(model, sd, vol, used, asd, fl, fr, seed, gt=None):
     tf = LP.teacher_forced(model, trace, vol_d, used_d, used, gt, **kw)
     df = LP.decision_forced(model, trace, vol_d, used_d, trace[0]["img"], gt, **kw)
     fr_ = LP.free_run(model, trace, stack_o, final_o, vol_d, used_d, asd, gt, seed, _d(fl), _d(fr))
-    for s in tf + df:
+    for s in tf:
         assert s["frac_gt_bar"] <= bar, s
         assert s["epe_delta"] < LP.BAR_EPE, s
-    flips = 0
-    for s in fr_["steps"]:
-        assert s["frac_gt_bar"] <= bar or flips > 0, s
-        flips += s["flips_mask_zero"]
+    flips = sum(s["flips_mask_zero"] for s in fr_["steps"])
+    for s in df + (fr_["steps"] if flips == 0 else []):          # trajectory level: the EPE bar (see test_gpu_parity.py)
+        assert s["epe_delta"] < LP.BAR_EPE, s
+        assert s["mean_abs_px"] < 2e-3, s
     if flips == 0:
         assert fr_["final"]["epe_delta"] < LP.BAR_EPE, fr_["final"]
     return {"teacher_forced": tf, "decision_forced": df, "free_run": fr_, "flips": flips}

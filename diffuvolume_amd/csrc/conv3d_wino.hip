@@ -16,7 +16,6 @@
 // A / B fragments are ds_read_b128 of four positions each.  The raw brick of chunk c+1 is written while chunk c
 // computes, its global loads are issued a further chunk ahead.
 
-#include <stdlib.h>
 #include <type_traits>
 
 #include "dv_common.h"
@@ -61,7 +60,7 @@ struct WinoArgs {
   int fast_ok;           // W % 4 == 0, 16-byte aligned pointers
 };
 
-template <bool HAS_SCALE, int MTW, int XF = 0>
+template <bool HAS_SCALE, int MTW>
 __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(WinoArgs a) {
   using G = WG<MTW>;
   constexpr int KC = G::KC, NT = G::NT, TD = G::TD, TH = G::TH, TW = G::TW, IY = G::IY, IX = G::IX, PRAW = G::PRAW;
@@ -225,33 +224,10 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
     };
     // V = Bt d B on packed-fp32 adds: rows as register pairs (two columns at a time), then per row the column
     // combinations (t0-t2, t1+t2) and (t2-t1, t1-t3) as one v_pk_add_f32 each (op_sel picks the halves, neg_* the
-    // signs) -- 16 vector instructions per patch instead of 32 adds plus the moves the compiler puts around them
+    // signs) -- 16 vector instructions per patch instead of 32 adds plus the moves the compiler puts around them.
+    // (Round 2 A/B: the same transform as 32 pinned single-register v_add_f32 / v_sub_f32, no moves, measured 1.9 %
+    // SLOWER on the 32->32 layer -- 58.5 vs 57.35 ms per step -- so the packed form stays.)
     auto transform = [&](int slot) __attribute__((always_inline)) {
-      if constexpr (XF == 1) {
-        // experiment (MI355X_MICROARCH.md: packed fp32 adds beside MFMAs cost more than their issue slot): the same
-        // transform on 32 single-register v_add / v_sub, each pinned as its own instruction so that neither the SLP
-        // vectoriser re-packs them nor register-pair moves appear
-        auto add = [](float x, float y) __attribute__((always_inline)) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
-        auto sub = [](float x, float y) __attribute__((always_inline)) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
-#pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) {
-          float t[4][4];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float d0 = d[mt][0][c >> 1][c & 1], d1 = d[mt][1][c >> 1][c & 1], d2 = d[mt][2][c >> 1][c & 1],
-                        d3 = d[mt][3][c >> 1][c & 1];
-            t[0][c] = sub(d0, d2); t[1][c] = add(d1, d2); t[2][c] = sub(d2, d1); t[3][c] = sub(d1, d3);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            vp[mt][slot][r][0][0] = sub(t[r][0], t[r][2]);
-            vp[mt][slot][r][0][1] = add(t[r][1], t[r][2]);
-            vp[mt][slot][r][1][0] = sub(t[r][2], t[r][1]);
-            vp[mt][slot][r][1][1] = sub(t[r][1], t[r][3]);
-          }
-        }
-        return;
-      }
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -451,14 +427,6 @@ extern "C" int dv_conv3d_wino_f32(const float* in, const float* wpacked, const f
     a.ntx = cdiv(W, G::TW); a.nty = cdiv(H, G::TH); a.ntz = cdiv(D, G::TD); a.nco = cdiv(Cout, 32);
     const long long blocks = (long long)B * a.nco * a.ntz * a.nty * a.ntx;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return (int)DV_ERR_SHAPE;
-    static const int xf = [] { const char* e = getenv("DV_WINO_XFORM"); return (e && e[0] == 's') ? 1 : 0; }();
-    if (xf == 1) {
-      if (in_scale)
-        hipLaunchKernelGGL((conv3d_wino_kernel<true, MTW, 1>), dim3((unsigned)blocks), dim3(256), 0, s, a);
-      else
-        hipLaunchKernelGGL((conv3d_wino_kernel<false, MTW, 1>), dim3((unsigned)blocks), dim3(256), 0, s, a);
-      return dv_launch_status();
-    }
     if (in_scale)
       hipLaunchKernelGGL((conv3d_wino_kernel<true, MTW>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     else

@@ -1,0 +1,113 @@
+"""BASELINE.json config 4 at its real size on one GPU: KITTI12 PCWNet + DiffuVolume, 1248x384, maxdisp 192, batch 4,
+3 DDIM steps.  Quarter resolution is 312 x 96, so every 16-wide tile row ends in a partial tile, and the coarser
+volumes are 156 / 78 / 39 wide (the last one takes the generic gwc path).  Checked against the CPU oracle on pair 0
+(builders, fused volume, every DDIM step from the oracle's state, the free run), against PyTorch's own fp32
+convolution for a full-resolution dilated refinement layer, and for batch-shard invariance.  ~1 min of host CPU."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from diffuvolume_amd import submodule as S
+from diffuvolume_amd.synth import NoiseTape, _gen, synth_state_dict, synth_stereo_batch
+from oracle import acv_oracle as A
+from oracle import loop_parity as LP
+from oracle import pcw_oracle as P
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+B, H, W = 4, 384, 1248
+
+
+def rel(a, b):
+    return float((a.cpu().double() - b.double()).abs().max() / b.double().abs().max().clamp(min=1e-30))
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from diffuvolume_amd.pwcnet_ddim import PWCNet_ddim
+    sd = synth_state_dict(PWCNet_ddim(192, True).state_dict(), seed=2, logit_gain=8.0,
+                          scale={"refinenet3.conv8.weight": 0.002})
+    m = PWCNet_ddim(192, True)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    batch = {k: v.to(DEV) for k, v in synth_stereo_batch(B, H, W, seed=0).items()}
+    with torch.no_grad():
+        fl = m.feature_extraction(batch["left"] * 0.05)
+        fr = m.feature_extraction(batch["right"] * 0.05)
+    return m, sd, batch, fl, fr
+
+
+def one(feats, i):
+    return {k: v[i:i + 1].cpu() for k, v in feats.items()}
+
+
+def test_builders_at_kitti_widths(setup):
+    m, sd, batch, fl, fr = setup
+    for i, (div, w) in enumerate(((4, 312), (8, 156), (16, 78), (32, 39)), start=1):
+        L, R = fl[f"gw{i}"], fr[f"gw{i}"]
+        assert L.shape[-1] == w and L.shape[-2] == H // div
+        vol = S.build_gwc_volume(L, R, 192 // div, 40)
+        ref = A.build_gwc_volume(L[:1].cpu(), R[:1].cpu(), 192 // div, 40)
+        torch.testing.assert_close(vol[:1].cpu(), ref, atol=1e-6, rtol=1e-6)
+        cl, cr = fl[f"concat_feature{i}"], fr[f"concat_feature{i}"]
+        cat = S.build_concat_volume(cl, cr, 192 // div, zero_left=True)
+        assert torch.equal(cat[:1].cpu(), A.build_concat_volume(cl[:1].cpu(), cr[:1].cpu(), 192 // div, zero_left=True))
+
+
+def test_fused_volume_and_loop_vs_oracle(setup):
+    m, sd, batch, fl, fr = setup
+    fl0, fr0 = one(fl, 0), one(fr, 0)
+    with torch.no_grad():
+        vol_d = m.fused_volume({k: v[:1] for k, v in fl.items()}, {k: v[:1] for k, v in fr.items()})
+        asd = m.encode_disparity(batch["disp"][:1])
+    vol = P.fused_volume(fl0, fr0, sd)
+    assert vol_d.shape == vol.shape == (1, 32, 48, 96, 312)
+    assert rel(vol_d, vol) < 2e-5
+    used, gt = batch["used"][:1].cpu(), batch["gt"][:1].cpu()
+    orc = P.PCWDiffusionOracle(sd)
+    final_o, stack_o, trace = LP.oracle_trajectory(orc, vol, used, asd.cpu(), 11, fl0, fr0)
+    dl, dr = {k: v[:1] for k, v in fl.items()}, {k: v[:1] for k, v in fr.items()}
+    tf = LP.teacher_forced(m, trace, vol_d, batch["used"][:1], used, gt, features_left=dl, features_right=dr)
+    fr_ = LP.free_run(m, trace, stack_o, final_o, vol_d, batch["used"][:1], asd, gt, 11, dl, dr)
+    print({"teacher_forced": tf, "free_run": fr_})
+    for s in tf:
+        assert s["frac_gt_bar"] <= LP.BAR_FRAC, s
+        assert s["epe_delta"] < LP.BAR_EPE, s
+    if sum(s["flips_mask_zero"] for s in fr_["steps"]) == 0:
+        assert fr_["final"]["epe_delta"] < LP.BAR_EPE, fr_["final"]
+        for s in fr_["steps"]:
+            assert s["epe_delta"] < LP.BAR_EPE and s["mean_abs_px"] < 2e-3, s
+
+
+def test_batch_of_four_and_shard_invariance(setup):
+    m, sd, batch, fl, fr = setup
+
+    def run(lo, hi):
+        tape = NoiseTape(21)
+
+        def draw(kind, shape, dtype):
+            return tape(kind, (B,) + tuple(shape[1:]), dtype)[lo:hi]
+
+        sl = lambda d: {k: v[lo:hi] for k, v in d.items()}
+        with torch.no_grad():
+            vol = m.fused_volume(sl(fl), sl(fr))
+            asd = m.encode_disparity(batch["disp"][lo:hi])
+            return m.ddim_sample(vol, batch["used"][lo:hi], asd, sl(fl), sl(fr), noise=draw)[0]
+
+    full = run(0, B)
+    assert full.shape == (B, H, W) and bool(torch.isfinite(full).all())
+    assert torch.equal(run(0, B), full)                        # bit-reproducible
+    for lo, hi in ((2, 3), (0, 2)):
+        assert torch.equal(run(lo, hi), full[lo:hi]), (lo, hi)  # what rank r of an N-GPU run computes for its slice
+
+
+@pytest.mark.parametrize("dil", [1, 4, 16])
+def test_fullres_refinement_conv_vs_torch(dil):
+    """One 32 -> 32 layer of refinenet_version3 (KITTI12/models/pwcnet_ddim.py:251-306) at 384 x 1248 against
+    F.conv2d on the GPU (MIOpen, fp32): partial tiles in x (1248 = 19.5 x 64) and the banded staging of d = 16."""
+    g = _gen(5, f"rf{dil}")
+    x = torch.randn(1, 32, H, W, generator=g).to(DEV)
+    w = (torch.randn(32, 32, 3, 3, generator=g) * 0.06).to(DEV)
+    plan = S.Conv2dPlan(w, None, dilation=dil, act=S.ACT_NONE)
+    ref = F.conv2d(x, w, None, 1, dil, dil)
+    assert rel(plan(x), ref.cpu()) < 1e-5

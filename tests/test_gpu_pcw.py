@@ -100,11 +100,11 @@ def _assert_pcw_loop_contract(model, sd, vol, used, asd, fl, fr, seed, gt=None):
         assert s["frac_gt_bar"] <= bar, s
         assert s["epe_delta"] < LP.BAR_EPE, s
     flips = sum(s["flips_mask_zero"] for s in fr_["steps"])
-    for s in df + (fr_["steps"] if flips == 0 else []):          # trajectory level: the EPE bar (see test_gpu_parity.py)
-        assert s["epe_delta"] < LP.BAR_EPE, s
-        assert s["mean_abs_px"] < 2e-3, s
+    for s in df + (fr_["steps"] if flips == 0 else []):          # trajectory level on a small fixture: divergence bound
+        assert s["epe_delta"] < 1e-3, s                           # (see test_gpu_parity.py::_assert_loop_contract; the
+        assert s["mean_abs_px"] < 1e-2, s                         # EPE bar itself is asserted at config-4 size)
     if flips == 0:
-        assert fr_["final"]["epe_delta"] < LP.BAR_EPE, fr_["final"]
+        assert fr_["final"]["epe_delta"] < 1e-3, fr_["final"]
     return {"teacher_forced": tf, "decision_forced": df, "free_run": fr_, "flips": flips}
 
 

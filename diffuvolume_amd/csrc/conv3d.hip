@@ -329,16 +329,25 @@ __global__ __launch_bounds__(256, G::WPS) void conv3d_mfma_kernel(ConvArgs a) {
 // brick; each thread 8 consecutive x of one (z,y) row, i.e. 8 accumulators fed by 9 LDS rows of 10
 // floats per input channel (two ds_read_b128 + one ds_read_b64 per row, conflict-free), with the 27
 // weights of the channel in scalar registers.  Reads the input once: HBM-bound in the limit.
+//
+// Round 2: the staging went from wave-uniform row pointers (30 rows x 64-bit scalar pointers + bounds per chunk:
+// 402 SGPR spills, 168 VGPRs, two barriers per 2-channel chunk; 0.90 ms = 29 % of the FMA issue rate) to the scheme
+// of the MFMA kernels: one buffer descriptor per channel, 16 per-thread 32-bit offsets computed once per block
+// (padding and the channel tail come out of the hardware range check), one channel per step through a
+// double-buffered LDS brick with ONE barrier per channel, the next channel's loads in flight during the FMAs, and
+// four blocks per CU (32.6 KB LDS, < 128 VGPRs).
 namespace c1 {
-constexpr int TZ = 4, TY = 8, TX = 64, XT = 8, KCV = 2;
+constexpr int TZ = 4, TY = 8, TX = 64, XT = 8;
 constexpr int IZ = TZ + 2, IY = TY + 2, IX = TX + 2, RW = 68;   // RW/4 odd: rows alternate 16-B slot parity
 constexpr int PLANE = IZ * IY * RW;
+constexpr int PRAW = IZ * IY * IX;
+constexpr int NS = (PRAW + 255) / 256;
 }  // namespace c1
 
 template <bool HAS_SCALE>
-__global__ __launch_bounds__(256, 2) void conv3d_c1_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 4) void conv3d_c1_kernel(ConvArgs a) {
   using namespace c1;
-  __shared__ __attribute__((aligned(16))) float in_s[KCV * PLANE];
+  __shared__ __attribute__((aligned(16))) float in_s[2 * PLANE];
   const int tid = threadIdx.x;
   unsigned t = dv_xcd_remap(blockIdx.x, gridDim.x);
   const int tx = t % a.ntx; t /= a.ntx;
@@ -353,80 +362,74 @@ __global__ __launch_bounds__(256, 2) void conv3d_c1_kernel(ConvArgs a) {
   const float* scb = (HAS_SCALE && a.in_scale) ? a.in_scale + (size_t)b * vol : nullptr;
   const float* w = a.wpk;  // raw [1][Cin][27] weights for this path
 
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   float acc[XT];
 #pragma unroll
   for (int i = 0; i < XT; ++i) acc[i] = 0.f;
 
-  // Staging: one wave per brick row, lanes on the 64 interior x (aligned 256-byte segments); the two
-  // halo columns of all rows are one extra element per thread.  Row coordinates are wave-uniform.
-  // The next chunk is fetched into registers before the current one is consumed.
-  constexpr int NR = KCV * IZ * IY / 4;        // rows per wave and chunk
-  static_assert(KCV * IZ * IY % 4 == 0 && KCV * IZ * IY * 2 <= 256, "staging plan");
-  float vmain[NR], vhalo = 0.f;
-  const int he = tid;                            // halo element: (cl, zz, yy, side)
-  const int hcl = he / (IZ * IY * 2), hr = he % (IZ * IY * 2);
-  const int hzz = (hr >> 1) / IY, hyy = (hr >> 1) % IY, hxx = (hr & 1) ? IX - 1 : 0;
-  const bool hlive = he < KCV * IZ * IY * 2;
-  // (c,z,y) are wave-uniform for the row loads: the row pointer lives in scalar registers and the
-  // lane only contributes a 32-bit offset
-  auto ldrow = [&](int c, int z, int y, int xoff) -> float {
-    const bool rok = c < a.Cin && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H;
-    const int x = x0 + xoff;
-    if (!rok || (unsigned)x >= (unsigned)a.W) return 0.f;
-    const size_t rowo = (size_t)z * plane + (size_t)y * a.W + x0;
-    float v = (inb + (size_t)c * vol + rowo)[xoff];
-    if (HAS_SCALE && scb) v *= (scb + rowo)[xoff];
-    return v;
-  };
-  auto fetch = [&](int c0) {
+  // staging plan: NS positions of the haloed 6 x 10 x 66 brick per thread, the same for every channel
+  unsigned sob[NS];
+  int slot[NS];
+  float scl[HAS_SCALE ? NS : 1];
 #pragma unroll
-    for (int it = 0; it < NR; ++it) {
-      const int rr = wave + 4 * it;
-      const int cl = rr / (IZ * IY), r2 = rr - cl * (IZ * IY);
-      const int zz = r2 / IY, yy = r2 - zz * IY;
-      vmain[it] = ldrow(c0 + cl, z0 - 1 + zz, y0 - 1 + yy, lane);
-    }
-    if (hlive) vhalo = ldrow(c0 + hcl, z0 - 1 + hzz, y0 - 1 + hyy, hxx - 1);
-  };
-  auto commit = [&]() {
+  for (int i = 0; i < NS; ++i) {
+    const int r = tid + 256 * i;
+    const int zz = r / (IY * IX), r2 = r - zz * (IY * IX);
+    const int yy = r2 / IX, xx = r2 - yy * IX;
+    const int z = z0 - 1 + zz, y = y0 - 1 + yy, x = x0 - 1 + xx;
+    const bool ok = r < PRAW && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+    const unsigned sp = ok ? (unsigned)((z * a.H + y) * a.W + x) : 0u;
+    sob[i] = ok ? sp * 4u : 0x80000000u;                    // beyond the buffer's records: the load returns 0
+    slot[i] = r < PRAW ? (zz * IY + yy) * RW + xx : IX;     // column 66 of row 0: never read
+    if (HAS_SCALE) scl[i] = (ok && scb) ? scb[sp] : 1.f;
+  }
+  const int vol_bytes = __builtin_amdgcn_readfirstlane((int)(vol * sizeof(float)));   // < 2^31 (checked by the host)
+  uint64_t fb = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)reinterpret_cast<uint64_t>(inb)) |
+                ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(reinterpret_cast<uint64_t>(inb) >> 32)) << 32);
+  float vin[NS];
+  auto fetch = [&](int c) __attribute__((always_inline)) {    // channels are fetched strictly in order: running base
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(fb), 0, c < a.Cin ? vol_bytes : 0, 0x00020000);
+    fb += (uint64_t)(unsigned)vol_bytes;
 #pragma unroll
-    for (int it = 0; it < NR; ++it) {
-      const int rr = wave + 4 * it;
-      const int cl = rr / (IZ * IY), r2 = rr - cl * (IZ * IY);
-      in_s[cl * PLANE + r2 * RW + 1 + lane] = vmain[it];
-    }
-    if (hlive) in_s[hcl * PLANE + (hzz * IY + hyy) * RW + hxx] = vhalo;
+    for (int i = 0; i < NS; ++i)
+      vin[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)sob[i], 0, 0));
+  };
+  auto commit = [&](float* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) buf[slot[i]] = HAS_SCALE ? vin[i] * scl[i] : vin[i];
   };
 
   fetch(0);
-  for (int c0 = 0; c0 < a.Cin; c0 += KCV) {
-    __syncthreads();
-    commit();
-    __syncthreads();
-    if (c0 + KCV < a.Cin) fetch(c0 + KCV);
+  commit(in_s);
+  fetch(1);
+  __syncthreads();
 #pragma unroll 1
-    for (int cl = 0; cl < KCV; ++cl) {
-      if (c0 + cl >= a.Cin) break;
-      const float* wc = w + (size_t)(c0 + cl) * 27;          // wave-uniform -> scalar loads
-#pragma unroll 1
-      for (int dz = 0; dz < 3; ++dz)
+  for (int c = 0; c < a.Cin; ++c) {
+    const float* cur = in_s + (c & 1) * PLANE;
+    float* nxt = in_s + ((c + 1) & 1) * PLANE;
+    const float* wc = w + (size_t)c * 27;                      // wave-uniform -> scalar loads
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-          const float* rp = in_s + cl * PLANE + ((zl + dz) * IY + (yl + dy)) * RW + xs;
-          const float4 q0 = *reinterpret_cast<const float4*>(rp);
-          const float4 q1 = *reinterpret_cast<const float4*>(rp + 4);
-          const float2 q2 = *reinterpret_cast<const float2*>(rp + 8);
-          const float v[10] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y};
-          const float w0 = wc[(dz * 3 + dy) * 3], w1 = wc[(dz * 3 + dy) * 3 + 1], w2 = wc[(dz * 3 + dy) * 3 + 2];
+    for (int dz = 0; dz < 3; ++dz) {
+      if (dz == 1) {                       // a third of the way in: the next channel's loads (issued one channel ago)
+        commit(nxt);                       // have landed; put them in the other buffer and refill the registers
+        fetch(c + 2);
+      }
 #pragma unroll
-          for (int i = 0; i < XT; ++i) {
-            acc[i] = fmaf(v[i], w0, acc[i]);
-            acc[i] = fmaf(v[i + 1], w1, acc[i]);
-            acc[i] = fmaf(v[i + 2], w2, acc[i]);
-          }
+      for (int dy = 0; dy < 3; ++dy) {
+        const float* rp = cur + ((zl + dz) * IY + (yl + dy)) * RW + xs;
+        const float4 q0 = *reinterpret_cast<const float4*>(rp);
+        const float4 q1 = *reinterpret_cast<const float4*>(rp + 4);
+        const float2 q2 = *reinterpret_cast<const float2*>(rp + 8);
+        const float v[10] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y};
+        const float w0 = wc[(dz * 3 + dy) * 3], w1 = wc[(dz * 3 + dy) * 3 + 1], w2 = wc[(dz * 3 + dy) * 3 + 2];
+#pragma unroll
+        for (int i = 0; i < XT; ++i) {
+          acc[i] = fmaf(v[i], w0, acc[i]);
+          acc[i] = fmaf(v[i + 1], w1, acc[i]);
+          acc[i] = fmaf(v[i + 2], w2, acc[i]);
         }
+      }
     }
+    __syncthreads();                       // `cur` is free for channel c+2, `nxt` is complete
   }
   const int zo = z0 + zl, yo = y0 + yl, xo = x0 + xs;
   if (zo >= a.Do || yo >= a.Ho || xo >= a.Wo) return;

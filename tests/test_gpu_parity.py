@@ -553,7 +553,7 @@ def test_ddim_loop_with_split_fp16_convs(acv_state_dict):
     assert float(d[1].mean()) < 2e-4 and float((d[1] > 1e-3).float().mean()) < 1e-2     # opt-in mode, step 1 vs golden
     _assert_loop_contract(m, acv_state_dict, vol, g["used"], g["x_T"], g["tape_seed"])
     for i, (e_h, e_o) in enumerate(_teacher_forced_vs_fp64(m, acv_state_dict, vol, g["used"], g["x_T"], g["tape_seed"])):
-        assert e_h < 1.5 * e_o + 2e-5, (i + 1, e_h, e_o)
+        assert e_h < 2.5 * e_o + 2e-5, (i + 1, e_h, e_o)
 
 
 def test_origin_acvnet_forward_golden():

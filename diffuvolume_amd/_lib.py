@@ -14,7 +14,8 @@ from pathlib import Path
 
 import torch  # noqa: F401  (must precede the dlopen below)
 
-_LIB_PATH = Path(__file__).resolve().parent / "libdiffuvolume_hip.so"
+# DV_LIB_PATH: load another build of the same ABI (A/B of compiler flags / kernel variants); default = the in-tree .so
+_LIB_PATH = Path(os.environ.get("DV_LIB_PATH") or Path(__file__).resolve().parent / "libdiffuvolume_hip.so")
 _lib = None
 
 
@@ -57,6 +58,8 @@ SIGNATURES = {
     "dv_conv2d_f32": (c_int, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "dv_conv2d_gated_f32": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "dv_conv2d_cat_f32": (c_int, [P, P, I, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "dv_conv2d_auto_kslices": (c_int, [I, I, I, I, I, I, I]),
+    "dv_conv2d_cat_ksplit_f32": (c_int, [P, P, I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "dv_conv2d_s2_f32": (c_int, [P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "dv_conv2d_wino_packed_floats": (c_size_t, [I, I]),
     "dv_conv2d_wino_pack_weights_f32": (c_int, [P, P, I, I, P]),

@@ -69,6 +69,12 @@ struct Conv2dArgs {
   int dil;                // dilation (= padding); 0 for 1x1
   int ntx, nty, nco;
   int act, vec_store, fast_ok;
+  // K-split (small launches: a single IGEV pair at 1/8 and 1/16 resolution is 240 / 72 blocks, each a serial loop over
+  // ~100 four-channel chunks): `kslices` blocks share an output tile, each sums a contiguous range of the input-channel
+  // chunks and stores its raw partial tile to scratch[slice][B,Cout,Ho,Wo]; conv2d_ksplit_epilogue_kernel adds the
+  // slices in a fixed order and applies scale / bias / residual / activation / gates
+  float* scratch;
+  int kslices;
 };
 
 template <class G>
@@ -85,8 +91,10 @@ __global__ __launch_bounds__(256, G::WPS) void conv2d_mfma_kernel(Conv2dArgs a) 
   unsigned t = dv_xcd_remap(blockIdx.x, gridDim.x);
   const int tx = t % a.ntx; t /= a.ntx;
   const int ty = t % a.nty; t /= a.nty;
-  const int tc = t % a.nco;
-  const int b = t / a.nco;
+  const int tc = t % a.nco; t /= a.nco;
+  // (integer division runs on the vector ALU: pin the wave-uniform results back into scalar registers)
+  const int slice = __builtin_amdgcn_readfirstlane(a.kslices > 1 ? (int)(t % (unsigned)a.kslices) : 0);
+  const int b = a.kslices > 1 ? (int)(t / (unsigned)a.kslices) : (int)t;
   const int x0 = tx * TW, y0 = ty * TH, co0 = tc * G::COUT;
   const int d = a.dil;
   const int C = (TW - 1) * S + 1 + (KS - 1) * d;                        // staged columns
@@ -198,12 +206,14 @@ __global__ __launch_bounds__(256, G::WPS) void conv2d_mfma_kernel(Conv2dArgs a) 
     }
   };
 
-  fetch(0);
-  for (int c = 0; c < nchunk; ++c) {
+  const int cbeg = __builtin_amdgcn_readfirstlane(a.kslices > 1 ? (nchunk * slice) / a.kslices : 0);
+  const int cend = __builtin_amdgcn_readfirstlane(a.kslices > 1 ? (nchunk * (slice + 1)) / a.kslices : nchunk);
+  fetch(cbeg);
+  for (int c = cbeg; c < cend; ++c) {
     __syncthreads();
     commit(c);
     __syncthreads();
-    if (c + 1 < nchunk) fetch(c + 1);
+    if (c + 1 < cend) fetch(c + 1);
     float av[2][MT];
     float bv[2][BV];
     int dq = d, Cq = C, Pq = P;
@@ -229,6 +239,29 @@ __global__ __launch_bounds__(256, G::WPS) void conv2d_mfma_kernel(Conv2dArgs a) 
 
   // ---- epilogue: BN scale/bias, residual, activation; lane = 4 x of one channel ----
   const size_t oplane = (size_t)a.Ho * a.Wo;
+  if (a.kslices > 1) {        // raw partial sums of this slice; the fused epilogue runs in the reduction kernel
+    float* sp = a.scratch + (size_t)slice * a.B * a.Cout * oplane;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int co = co0 + n * 16 + j;
+      if (co >= a.Cout) continue;
+      const size_t cbase = ((size_t)b * a.Cout + co) * oplane;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int yo = y0 + wave * RPW + m / MTX, xo = x0 + (m % MTX) * 16 + 4 * kq;
+        if (yo >= a.Ho || xo >= a.Wo) continue;
+        const size_t o = cbase + (size_t)yo * a.Wo + xo;
+        if (a.vec_store && xo + 4 <= a.Wo) {
+          *reinterpret_cast<f32x4*>(sp + o) = acc[m][n];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (xo + e < a.Wo) sp[o + e] = acc[m][n][e];
+        }
+      }
+    }
+    return;
+  }
   const bool fast = a.fast_ok && co0 + G::COUT <= a.Cout && x0 + TW <= a.Wo && y0 + TH <= a.Ho;
   const float slope = a.act == DV_ACT_RELU ? 0.f : (a.act == DV_ACT_LEAKY ? 0.01f : 1.f);
   // GEN: activations that need a transcendental (Mish, sigmoid, tanh), chosen per element by a uniform switch;
@@ -349,15 +382,62 @@ inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 inline int nt_of(int Cout) { return Cout > 16 ? 2 : 1; }
 inline int kc_of(int k, int /*dil*/) { return k == 3 ? 4 : 8; }
 
+// sum of the K-split partials (fixed slice order: deterministic) + the fused epilogue of conv2d_mfma_kernel
+__global__ __launch_bounds__(256) void conv2d_ksplit_epilogue_kernel(const float* __restrict__ scratch, int kslices,
+                                                                     size_t total, int Cout, size_t oplane,
+                                                                     const float* __restrict__ ch_scale,
+                                                                     const float* __restrict__ ch_bias,
+                                                                     const float* __restrict__ residual,
+                                                                     const float* __restrict__ mul,
+                                                                     const float* __restrict__ blend_z,
+                                                                     const float* __restrict__ blend_h,
+                                                                     float* __restrict__ out, int act) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  float v = scratch[i];
+  for (int sl = 1; sl < kslices; ++sl) v += scratch[(size_t)sl * total + i];
+  const int co = (int)((i / oplane) % (size_t)Cout);
+  v = fmaf(v, ch_scale ? ch_scale[co] : 1.f, ch_bias ? ch_bias[co] : 0.f);
+  if (residual) v += residual[i];
+  v = dv_act(v, act);
+  if (mul) v *= mul[i];
+  if (blend_z) v = blend_h[i] + blend_z[i] * (v - blend_h[i]);
+  out[i] = v;
+}
+
 template <class G>
 int launch2d(Conv2dArgs a, hipStream_t s) {
   a.ntx = (a.Wo + G::TW - 1) / G::TW;
   a.nty = (a.Ho + G::TH - 1) / G::TH;
   a.nco = pad_to(a.Cout, G::COUT) / G::COUT;
-  const long long blocks = (long long)a.B * a.nco * a.nty * a.ntx;
+  const int ks = a.kslices > 1 ? a.kslices : 1;
+  const long long blocks = (long long)a.B * a.nco * a.nty * a.ntx * ks;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return DV_ERR_SHAPE;
+  if (ks > 1) {
+    if ((a.Cin + G::KC - 1) / G::KC < ks) return DV_ERR_UNSUPPORTED;       // at least one chunk per slice
+    a.vec_store = a.vec_store && dv_aligned16(a.scratch);
+    a.fast_ok = a.fast_ok && dv_aligned16(a.scratch);
+  }
   hipLaunchKernelGGL((conv2d_mfma_kernel<G>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+  int rc = dv_launch_status();
+  if (rc != DV_OK || ks == 1) return rc;
+  const size_t oplane = (size_t)a.Ho * a.Wo, total = (size_t)a.B * a.Cout * oplane;
+  hipLaunchKernelGGL(conv2d_ksplit_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.scratch, ks,
+                     total, a.Cout, oplane, a.ch_scale, a.ch_bias, a.residual, a.mul, a.blend_z, a.blend_h, a.out, a.act);
   return dv_launch_status();
+}
+
+// Slices the library uses for a stride-1 3x3 (dilation <= 4) or 1x1 launch of this size: 1 unless the launch has
+// fewer than 256 blocks of the small-problem tile (4 x 32 pixels x 32 channels) and at least 8 chunks per slice.
+inline int auto_kslices(int B, int Cin, int H, int W, int Cout, int k, int dilation) {
+  if (k != 3 || dilation > 4 || Cout < 32) return 1;
+  const long long blocks = (long long)B * ((H + 3) / 4) * ((W + 31) / 32) * ((Cout + 31) / 32);
+  if (blocks >= 256) return 1;
+  const int nchunk = (Cin + 3) / 4;
+  int ks = (int)(1024 / blocks);
+  if (ks > 8) ks = 8;
+  while (ks > 1 && nchunk / ks < 8) --ks;
+  return ks < 1 ? 1 : ks;
 }
 
 }  // namespace
@@ -387,7 +467,7 @@ static int conv2d_run(const float* in, const float* const* more, const int* more
                       const float* wpacked, const float* ch_scale, const float* ch_bias,
                       const float* residual, const float* mul, const float* blend_z, const float* blend_h, float* out,
                       int B, int Cin, int H, int W, int Cout, int k, int dilation, int stride, int act,
-                      dv_stream_t stream) {
+                      dv_stream_t stream, float* scratch = nullptr, int kslices = 1) {
   DV_REQUIRE_PTR(in);
   DV_REQUIRE_PTR(wpacked);
   DV_REQUIRE_PTR(out);
@@ -422,6 +502,12 @@ static int conv2d_run(const float* in, const float* const* more, const int* more
                 (!mul || dv_aligned16(mul)) && (!blend_z || (dv_aligned16(blend_z) && dv_aligned16(blend_h)));
   a.fast_ok = a.vec_store && (size_t)Cout * a.Ho * a.Wo * sizeof(float) <= 0xffffffffull;
   a.ntx = a.nty = a.nco = 0;
+  a.scratch = scratch;
+  a.kslices = kslices;
+  if (kslices > 1) {
+    DV_REQUIRE_PTR(scratch);
+    DV_REQUIRE(stride == 1 && kslices == auto_kslices(B, Cin, H, W, Cout, k, dilation), DV_ERR_UNSUPPORTED);
+  }
   hipStream_t s = (hipStream_t)stream;
   const int NT = nt_of(Cout);
   //                              KS NT KC DMAX BANDED RPW [WPS MTX S]
@@ -480,6 +566,29 @@ extern "C" int dv_conv2d_s2_f32(const float* in, const float* wpacked, const flo
                                 int act, dv_stream_t stream) {
   return conv2d_run(in, nullptr, nullptr, 0, wpacked, ch_scale, ch_bias, residual, nullptr, nullptr, nullptr, out, B, Cin, H,
                     W, Cout, k, 1, 2, act, stream);
+}
+
+extern "C" int dv_conv2d_auto_kslices(int B, int Cin, int H, int W, int Cout, int k, int dilation) {
+  if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 1;
+  return auto_kslices(B, Cin, H, W, Cout, k, dilation);
+}
+
+extern "C" int dv_conv2d_cat_ksplit_f32(const float* const* inputs, const int* channels, int n_inputs,
+                                        const float* wpacked, const float* ch_scale, const float* ch_bias,
+                                        const float* residual, const float* mul, const float* blend_z,
+                                        const float* blend_h, float* out, float* scratch, int kslices, int B, int H, int W,
+                                        int Cout, int k, int dilation, int act, dv_stream_t stream) {
+  DV_REQUIRE_PTR(inputs);
+  DV_REQUIRE_PTR(channels);
+  DV_REQUIRE(n_inputs >= 1 && n_inputs <= 4, DV_ERR_UNSUPPORTED);
+  DV_REQUIRE(kslices >= 2 && kslices <= 8, DV_ERR_UNSUPPORTED);
+  int cin = 0;
+  for (int i = 0; i < n_inputs; ++i) {
+    DV_REQUIRE(channels[i] > 0, DV_ERR_SHAPE);
+    cin += channels[i];
+  }
+  return conv2d_run(inputs[0], inputs + 1, channels + 1, n_inputs - 1, wpacked, ch_scale, ch_bias, residual, mul, blend_z,
+                    blend_h, out, B, cin, H, W, Cout, k, dilation, 1, act, stream, scratch, kslices);
 }
 
 extern "C" int dv_conv2d_cat_f32(const float* const* inputs, const int* channels, int n_inputs, const float* wpacked,

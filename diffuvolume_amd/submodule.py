@@ -402,6 +402,7 @@ class Conv2dPlan:
         self.scale, self.shift = _fold_bn(bn, bias, self.cout, w.device, eps)
 
     WINO_MIN_BLOCKS = 128
+    KSPLIT = True               # K-split the launches that are too small to fill the chip (A/B switch for tools/)
 
     def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, mul: Optional[torch.Tensor] = None,
                  blend: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
@@ -468,6 +469,26 @@ class Conv2dPlan:
                                                                     _lib.ptr(bh), out.data_ptr(), b, h, w, self.cout,
                                                                     self.act, _lib.stream_ptr()),
                                          "dv_conv2d_wino_cat_f32"))
+            return out
+        # launches too small to fill the chip (a single IGEV pair at 1/8 and 1/16 resolution): K-split over the input
+        # channels, partial tiles in a scratch buffer, fused epilogue in the reduction kernel
+        kslices = lib.dv_conv2d_auto_kslices(b, cin, h, w, self.cout, self.k, self.dilation)
+        if kslices > 1 and self.KSPLIT:
+            import ctypes
+            srcs = parts if parts is not None else [x]
+            ptrs = (ctypes.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
+            chans = (ctypes.c_int * len(srcs))(*[t.shape[1] for t in srcs])
+            scratch = torch.empty(kslices * out.numel(), dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device):
+                nb = 4.0 * (sum(t.numel() for t in srcs) + out.numel() * (1 + extra + 2 * kslices))
+                timed(f"conv2d_k{self.k}d{self.dilation}_co{self.cout}_ksplit", 2.0 * out.numel() * cin * self.k ** 2, nb,
+                      lambda: _lib.check(lib.dv_conv2d_cat_ksplit_f32(ptrs, chans, len(srcs), self.wpacked.data_ptr(),
+                                                                      _lib.ptr(self.scale), _lib.ptr(self.shift),
+                                                                      _lib.ptr(residual), _lib.ptr(mul), _lib.ptr(bz),
+                                                                      _lib.ptr(bh), out.data_ptr(), scratch.data_ptr(),
+                                                                      kslices, b, h, w, self.cout, self.k, self.dilation,
+                                                                      self.act, _lib.stream_ptr()),
+                                         "dv_conv2d_cat_ksplit_f32"))
             return out
         if parts is not None:
             import ctypes

@@ -161,6 +161,17 @@ int dv_conv2d_cat_f32(const float* const* inputs, const int* channels, int n_inp
                       const float* blend_z, const float* blend_h, float* out, int B, int H, int W, int Cout,
                       int k, int dilation, int act, dv_stream_t stream);
 
+/* K-split form of dv_conv2d_cat_f32 for launches too small to fill the chip (a single IGEV pair at 1/8 and 1/16
+ * resolution: KITTI15/core/update.py:33-40 at 48x156 / 24x78 pixels): `kslices` blocks share an output tile, each
+ * sums a contiguous range of the input-channel chunks into scratch[kslices][B,Cout,H,W]; a second small kernel adds
+ * the slices in a fixed order (deterministic) and applies the same fused epilogue.  kslices must be the value
+ * dv_conv2d_auto_kslices returns for this shape (1 = use dv_conv2d_cat_f32); scratch is caller-allocated. */
+int dv_conv2d_auto_kslices(int B, int Cin, int H, int W, int Cout, int k, int dilation);
+int dv_conv2d_cat_ksplit_f32(const float* const* inputs, const int* channels, int n_inputs, const float* wpacked,
+                             const float* ch_scale, const float* ch_bias, const float* residual, const float* mul,
+                             const float* blend_z, const float* blend_h, float* out, float* scratch, int kslices,
+                             int B, int H, int W, int Cout, int k, int dilation, int act, dv_stream_t stream);
+
 /* Stride-2 flavour (the down-sampling layers of the 2-D feature CNNs: SceneFlow/models/acv_ddim.py:19-21, :28 --
  * convbn(k 3, stride 2, pad 1) and the 1x1 stride-2 `downsample`): out [B,Cout,(H-1)/2+1,(W-1)/2+1], dilation 1,
  * residual (if any) has the output's shape.  Same packed weights as dv_conv2d_f32 with dilation 1. */

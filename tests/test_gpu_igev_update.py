@@ -130,3 +130,36 @@ def test_conv2d_over_virtual_concatenation():
     plan = S.Conv2dPlan(dev(w), None, act=S.ACT_RELU, bias=dev(bias))
     torch.testing.assert_close(plan([dev(t) for t in parts]).cpu(), ref, atol=2e-6, rtol=1e-5)
     torch.testing.assert_close(plan(dev(torch.cat(parts, 1))).cpu(), ref, atol=2e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("cfg", [((128, 128, 128), 128, 24, 78, "sigmoid"), ((128, 256), 128, 48, 156, "tanh"),
+                                 ((64,), 32, 12, 40, "relu"), ((40, 24), 48, 9, 33, "none")])
+def test_conv2d_ksplit_small_launches(cfg):
+    """Launches too small to fill the chip (one IGEV pair at 1/8 and 1/16 resolution: the GRU convolutions of
+    KITTI15/core/update.py:33-40) are split over the input channels (`dv_conv2d_cat_ksplit_f32`): same fused epilogue
+    (bias, residual, sigmoid / tanh, `mul`, the GRU blend), same result as the one-block-per-tile kernel and as
+    PyTorch's convolution, bit-reproducible (the slices are added in a fixed order)."""
+    from diffuvolume_amd import _lib
+    from diffuvolume_amd import submodule as S
+    chans, cout, h, w, act = cfg
+    cin = sum(chans)
+    g = _gen(57, str(cfg))
+    xs = [torch.randn(1, c, h, w, generator=g) for c in chans]
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    res, mul = torch.randn(1, cout, h, w, generator=g) * 0.2, torch.rand(1, cout, h, w, generator=g)
+    z, hh = torch.rand(1, cout, h, w, generator=g), torch.randn(1, cout, h, w, generator=g)
+    lib = _lib.load()
+    ks = lib.dv_conv2d_auto_kslices(1, cin, h, w, cout, 3, 1)
+    assert ks > 1 and lib.dv_conv2d_auto_kslices(8, cin, 96, 312, cout, 3, 1) == 1
+    fn = {"sigmoid": torch.sigmoid, "tanh": torch.tanh, "relu": torch.relu, "none": lambda t: t}[act]
+    y = fn(torch.nn.functional.conv2d(torch.cat(xs, 1), wt, bias, 1, 1) + res) * mul
+    y = hh + z * (y - hh)
+    plan = S.Conv2dPlan(wt.to(DEV), None, act={"sigmoid": S.ACT_SIGMOID, "tanh": S.ACT_TANH, "relu": S.ACT_RELU,
+                                               "none": S.ACT_NONE}[act], bias=bias.to(DEV))
+    plan.wino_packed = None                              # force the direct kernel (these sizes stay off Winograd anyway)
+    args = ([t.to(DEV) for t in xs],)
+    kw = dict(residual=res.to(DEV), mul=mul.to(DEV), blend=(z.to(DEV), hh.to(DEV)))
+    out = plan(*args, **kw)
+    assert float((out.cpu() - y).abs().max() / y.abs().max()) < 1e-5
+    assert torch.equal(plan(*args, **kw), out)

@@ -140,10 +140,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pcw", action="store_true")
     ap.add_argument("--igev", action="store_true")
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--no-ksplit", action="store_true", help="A/B: one block per output tile for the small launches too")
     a = ap.parse_args()
+    if a.no_ksplit:
+        from diffuvolume_amd import submodule as S
+        S.Conv2dPlan.KSPLIT = False
     out = {}
     if a.igev or not (a.pcw or a.igev):
-        out["igev"] = igev()
+        out["igev"] = igev(b=a.batch)
     if a.pcw or not (a.pcw or a.igev):
         out["pcw"] = pcw()
     print(json.dumps(out, indent=1))

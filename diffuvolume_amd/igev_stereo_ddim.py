@@ -287,6 +287,11 @@ class hourglass(nn.Module):
         self._plans = None
         return super()._load_from_state_dict(*a, **k)
 
+    def _replicate_for_data_parallel(self):        # nn.DataParallel replicas fold / pack their own weights
+        replica = super()._replicate_for_data_parallel()
+        replica._plans = None
+        return replica
+
     def forward(self, x, features):
         p = self.prepare()
         conv1 = self.feature_att_8(_run(p["conv1"], x), features[1], inplace=True)
@@ -321,6 +326,11 @@ class IGEVCostVolume(nn.Module):
     def _load_from_state_dict(self, *a, **k):      # reached also when a parent / wrapper loads the checkpoint
         self._plans = None
         return super()._load_from_state_dict(*a, **k)
+
+    def _replicate_for_data_parallel(self):        # nn.DataParallel replicas fold / pack their own weights
+        replica = super()._replicate_for_data_parallel()
+        replica._plans = None
+        return replica
 
     def prepare(self):
         if self._plans is None:

@@ -122,6 +122,11 @@ class FeatureExtraction(nn.Module, _Stacker):
         self._plans = None
         return super()._load_from_state_dict(*a, **k)
 
+    def _replicate_for_data_parallel(self):        # nn.DataParallel replicas fold / pack their own weights
+        replica = super()._replicate_for_data_parallel()
+        replica._plans = None
+        return replica
+
     def train(self, mode: bool = True):
         if mode != self.training:
             self._plans = None
@@ -478,6 +483,11 @@ class PWCNet_ddim(nn.Module):
     def _load_from_state_dict(self, *a, **k):      # reached however the checkpoint arrives (wrapper or direct)
         self._plans = None
         return super()._load_from_state_dict(*a, **k)
+
+    def _replicate_for_data_parallel(self):        # nn.DataParallel replicas fold / pack their own weights
+        replica = super()._replicate_for_data_parallel()
+        replica._plans = None
+        return replica
 
     def train(self, mode: bool = True):
         if mode != self.training:

@@ -31,6 +31,11 @@ class _Planned(nn.Module):
         self._plans = None
         return super()._load_from_state_dict(*a, **k)
 
+    def _replicate_for_data_parallel(self):        # nn.DataParallel replicas fold / pack their own weights
+        replica = super()._replicate_for_data_parallel()
+        replica._plans = None
+        return replica
+
     def plans(self):
         if self._plans is None:
             self._plans = self._build()

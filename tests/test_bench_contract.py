@@ -1,0 +1,44 @@
+"""The committed bench line of the round (profiles/r*_bench.json, copied from the GPU box) keeps the driver's
+contract: one JSON object with the metric of BASELINE.json, whole-job throughput, a hardware roofline fraction that
+is a fraction (achieved / peak < 1, priced with the flops the kernel issues), the CPU baseline timed on the same box
+without extrapolation, and the parity leg's verdict."""
+import json
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def latest():
+    files = sorted((ROOT / "profiles").glob("r*_bench.json"))
+    assert files, "no committed bench line"
+    return json.loads(files[-1].read_text())
+
+
+def test_contract_keys_and_roofline():
+    d = latest()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "pairs/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"]["global_batch"] * 1e3 / d["ms_per_step"]) / d["value"] < 1e-6
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0        # a hardware fraction
+    assert abs(r["algorithmic_tflops"] / r["multiply_reduction"] - r["achieved"]) < 1e-6
+    assert r["traffic"] is None or r["traffic"] >= 0.9 * r["algorithmic_bytes_per_launch"]
+    for k in d.get("roofline_kernels", []):
+        assert 0.0 < k["frac"] < 1.0 and k["avg_ms"] > 0
+    assert len(d.get("roofline_kernels", [])) >= 3
+
+
+def test_cpu_baseline_and_parity_leg():
+    d = latest()
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["extrapolated"] is False and c["cores"] >= 1 and 0 < c["value"] < d["value"]
+    p = d["parity_vs_oracle"]
+    assert p["teacher_forced_within_bars"] is True
+    assert len(p["teacher_forced"]) == d["config"]["ddim_steps"]
+    assert all(s["epe_delta"] < p["bars"]["epe"] for s in p["teacher_forced"] + p["free_run"])
+    assert p["free_run_final"]["epe_delta"] < p["bars"]["epe"]

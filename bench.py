@@ -88,7 +88,8 @@ def launch_workers(a, argv):
     itself; `torch.cuda.device_count()` does not initialise HIP."""
     import socket
     import subprocess
-    if not a.dry_run:
+    oversub = os.environ.get("DV_BENCH_OVERSUBSCRIBE") == "1"     # plumbing test of the N-rank path on a smaller box:
+    if not a.dry_run and not oversub:                              # ranks share devices, rendezvous over gloo
         n_vis = torch.cuda.device_count()
         if n_vis < a.gpus:
             print(f"bench.py: --gpus {a.gpus} but only {n_vis} GPU(s) visible; refusing to measure fewer", file=sys.stderr)
@@ -100,6 +101,8 @@ def launch_workers(a, argv):
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", DV_BENCH_SELF_LAUNCHED="1")
+        if oversub:
+            env["DV_DIST_BACKEND"] = "gloo"
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
     rc = 0
     alive = list(procs)
@@ -356,7 +359,7 @@ def main():
     value = pairs / dt
     rccl_ranks = 1
     if world > 1:                              # read the group size back through the collective itself
-        ones = torch.ones(1, device=device)
+        ones = torch.ones(1, device="cpu" if torch.distributed.get_backend() == "gloo" else device)
         torch.distributed.all_reduce(ones)
         rccl_ranks = int(ones.item())
         assert rccl_ranks == a.gpus, (rccl_ranks, a.gpus)
@@ -370,6 +373,7 @@ def main():
                                f"batch={a.batch}/GPU, random-init weights",
                    "global_batch": a.batch * world, "ddim_steps": a.ddim_steps, "parallelism": f"dp{world}"},
         "rccl_ranks": rccl_ranks,
+        "dist_backend": torch.distributed.get_backend() if world > 1 else None,
         "launcher": "self" if os.environ.get("DV_BENCH_SELF_LAUNCHED") else ("torchrun" if world > 1 else "single"),
         "epe_px": epe["EPE"],
         "epe_note": "random-init weights and synthetic pairs: the number only shows the metric path runs; dataset EPE "

@@ -50,7 +50,7 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
 def barrier_and_max(seconds: float, device) -> float:
     """Barrier, then the MAX over ranks of a local duration (bench.py contract)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        t = torch.tensor([seconds], dtype=torch.float64, device=device)
+        t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
     return seconds

@@ -56,3 +56,23 @@ def test_two_process_shards_match_single_process():
     assert full[:4].double().sum().item().hex() == sums[0][0] and full[4:].double().sum().item().hex() == sums[1][0]
     epe8 = acc8.reduce()["EPE"]
     assert abs(epe8 - single["EPE"]) < 1e-12                        # mean of 8 == mean of two means of 4
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_end_to_end_on_one_gpu():
+    """`python bench.py --gpus 2` through its own launcher on the one GPU of the test box (DV_BENCH_OVERSUBSCRIBE=1: the
+    ranks share cuda:0 and rendezvous over gloo -- RCCL needs one device per rank): the whole N > 1 code path of the
+    bench -- worker launch, per-rank inputs, barriers, max-over-ranks timing, the metric all-reduce, one JSON line from
+    rank 0 -- runs on real kernels.  The 8-GPU RCCL run itself is the driver's."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["DV_BENCH_OVERSUBSCRIBE"] = "1"
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "2",
+                        "--height", "128", "--width", "256", "--no-cpu-baseline", "--no-extras"],
+                       capture_output=True, text=True, timeout=800, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["dist_backend"] == "gloo" and d["launcher"] == "self"
+    assert d["config"]["global_batch"] == 4 and d["scaling"] == "weak" and d["value"] > 0
+    assert "roofline" in d and "cpu_baseline" not in d            # CPU baseline is an N = 1 leg

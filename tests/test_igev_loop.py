@@ -58,4 +58,7 @@ def test_hip_loop_matches_reference_methods():
     final = loop.ddim_sample(i, i, None, 3, [None], [None], geo_fn, g["used"].to(dev), g["asd"].to(dev), None,
                              noise=NoiseTape(g["tape_seed"]))
     d = (final.cpu() - g["final"]).abs()
-    assert float(d.median()) < 1e-4 and float(d.mean()) < 1e-2, (float(d.median()), float(d.mean()))
+    # the contract's bars against the reference's own output (measured: mean 1.6e-6 px, max 1.5e-5 px, |dEPE| 5e-9)
+    assert float(d.max()) < 1e-3 and float(d.mean()) < 1e-4, (float(d.max()), float(d.mean()))
+    u = g["used"].reshape(g["final"].shape)
+    assert abs(float((final.cpu() - u).abs().mean()) - float((g["final"] - u).abs().mean())) < 1e-4

@@ -108,11 +108,17 @@ def test_forward_matches_the_reference_class():
     steps = torch.stack([s.reshape(g["step_disp"].shape[1:]) for s in seen]).cpu()
     d1 = (steps[0] - g["step_disp"][0]).abs()
     # step 1 (before any renewal decision is fed back): the contract's bar against the reference's own output
-    assert float(d1.mean()) < 2e-4 and float((d1 > 1e-3).float().mean()) <= 1e-2, (float(d1.mean()), float(d1.max()))
+    # (measured: mean 6.4e-5 px, max 4.9e-4 px)
+    assert float(d1.mean()) < 2e-4 and float(d1.max()) < 1e-3, (float(d1.mean()), float(d1.max()))
     d = (pred.cpu() - g["pred"]).abs()
-    assert float(d.median()) < 1e-4, float(d.median())
+    print("igev model vs reference class: step1 mean", float(d1.mean()), "max", float(d1.max()), "frac>1e-3",
+          float((d1 > 1e-3).float().mean()), "| final mean", float(d.mean()), "max", float(d.max()), "frac>1e-3",
+          float((d > 1e-3).float().mean()))
+    # final output: every pixel within 1e-3 px of the reference class's output, EPE within 1e-4 (measured: mean
+    # 1.8e-6 px, max 2.0e-4 px)
+    assert float(d.max()) < 1e-3 and float(d.mean()) < 1e-4, (float(d.max()), float(d.mean()))
     gt = flow_full[0].cpu()
-    assert abs(float((pred.cpu() - gt).abs().mean()) - float((g["pred"] - gt).abs().mean())) < 1e-3
+    assert abs(float((pred.cpu() - gt).abs().mean()) - float((g["pred"] - gt).abs().mean())) < 1e-4
 
 
 @pytest.mark.gpu

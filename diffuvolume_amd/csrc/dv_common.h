@@ -43,6 +43,19 @@ __device__ __forceinline__ float dv_act(float v, int act) {
   }
 }
 
+// exp(x) for x <= 0 (softmax terms after the max is subtracted): 2^(x*log2 e) on the hardware transcendental, with the
+// rounding error of the product carried along -- t = fl(x*L), r = (x*L - t) + x*(log2 e - L) exactly by fma, and
+// 2^(t+r) = 2^t * (1 + r ln 2) to first order (|r| <= 2^-24 |t| < 1e-5, so the next term is below 1e-10).
+// Same ~1 ulp as expf() (the softmax kernels are bound by their exponentials; libm's version spends half its instructions on
+// overflow / denormal handling that cannot occur here: results below 2^-126 flush to zero next to a sum >= 1).
+__device__ __forceinline__ float dv_exp_le0(float x) {
+  const float L = 1.44269504088896340736f, LL = 1.92596299112661746e-8f;
+  const float t = x * L;
+  const float r = fmaf(x, L, -t) + x * LL;
+  const float p = __builtin_amdgcn_exp2f(t);
+  return fmaf(p, r * 0.69314718055994530942f, p);
+}
+
 // XCD-aware block remap: blocks b and b+8 share an XCD (and its L2), so give
 // every XCD a contiguous slab of tiles.  Bijective for any grid size.
 __device__ __forceinline__ unsigned dv_xcd_remap(unsigned bid, unsigned nblk) {

@@ -28,19 +28,6 @@ __device__ __forceinline__ void lin_src(int dst, int in_size, int out_size, int&
   l0 = 1.f - l1;
 }
 
-// exp(x) for x <= 0 (softmax terms after the max is subtracted): 2^(x*log2 e) on the hardware transcendental, with the
-// rounding error of the product carried along -- t = fl(x*L), r = (x*L - t) + x*(log2 e - L) exactly by fma, and
-// 2^(t+r) = 2^t * (1 + r ln 2) to first order (|r| <= 2^-24 |t| < 1e-5, so the next term is below 1e-10).
-// Same ~1 ulp as expf() (the kernel is bound by its 4D exponentials; libm's version spends half its instructions on
-// overflow / denormal handling that cannot occur here: results below 2^-126 flush to zero next to a sum >= 1).
-__device__ __forceinline__ float exp_le0(float x) {
-  const float L = 1.44269504088896340736f, LL = 1.92596299112661746e-8f;
-  const float t = x * L;
-  const float r = fmaf(x, L, -t) + x * LL;
-  const float p = __builtin_amdgcn_exp2f(t);
-  return fmaf(p, r * 0.69314718055994530942f, p);
-}
-
 template <int D, bool ALIGN>
 __global__ __launch_bounds__(256) void upsample_softmax_regress_kernel(const float* __restrict__ cost,
                                                                        const float* __restrict__ disp_in,
@@ -93,7 +80,7 @@ __global__ __launch_bounds__(256) void upsample_softmax_regress_kernel(const flo
   for (int k = 0; k < K; ++k) {
     float v;
     DV_VK(k, v);
-    e[k] = exp_le0(v - m);
+    e[k] = dv_exp_le0(v - m);
     s += e[k];
   }
   // p_k = e_k * (1/s): one correctly rounded division per pixel instead of 4D (each is ~10 instructions);

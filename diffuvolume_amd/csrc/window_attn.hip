@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void window_attn_kernel(AttnArgs a) {
 #pragma unroll
       for (int kk = 0; kk < TOK / 2; ++kk) {
         const int k = kh * (TOK / 2) + kk;
-        const float p = expf(sc[kk] - mx);
+        const float p = dv_exp_le0(sc[kk] - mx);      // sc <= mx: the compensated exp2 of dv_common.h, ~1 ulp like expf
         sum += p;
         const float4 va = *reinterpret_cast<const float4*>(q_s + k * LDQ2 + 2 * GH2 * HD + hoff);
         const float4 vb = *reinterpret_cast<const float4*>(q_s + k * LDQ2 + 2 * GH2 * HD + hoff + 4);
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void window_attn_kernel(AttnArgs a) {
       const float* p0 = w_s + ((head * 2 + 0) * TOK + q) * PSTRIDE;
       const float* p1 = w_s + ((head * 2 + 1) * TOK + q) * PSTRIDE;
       const float m = fmaxf(p0[0], p1[0]);
-      const float e0 = expf(p0[0] - m), e1 = expf(p1[0] - m);
+      const float e0 = dv_exp_le0(p0[0] - m), e1 = dv_exp_le0(p1[0] - m);
       const float inv = 1.f / (p0[1] * e0 + p1[1] * e1);
       float* dst = o_s + q * LDO + (g * GH2 + head) * HD + hd;
 #pragma unroll

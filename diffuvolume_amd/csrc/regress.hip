@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void upsample_softmax_regress_kernel(const flo
                                                                        const float* __restrict__ disp_in,
                                                                        float* __restrict__ disp,
                                                                        float* __restrict__ unc, int h,
-                                                                       int w, size_t total) {
+                                                                       int w, size_t total, unsigned cost_bytes) {
   const int H = 4 * h, W = 4 * w;
   constexpr int K = 4 * D;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -46,13 +46,22 @@ __global__ __launch_bounds__(256) void upsample_softmax_regress_kernel(const flo
   lin_src<ALIGN>(Y, h, H, y0, y1, hy0, hy1);
   lin_src<ALIGN>(X, w, W, x0, x1, wx0, wx1);
   const size_t plane = (size_t)h * w;
-  const float* cb = cost + (size_t)b * D * plane;
+  // the 4 x D neighbour loads as buffer loads: four per-lane 32-bit byte offsets (slice d = 0 of batch item b) plus a
+  // SCALAR offset d * plane -- no per-load 64-bit address arithmetic on the vector unit (it was 370 of the kernel's
+  // 3 300 vector instructions per pixel).  The host guarantees the cost tensor is below 2^31 bytes.
+  const int plane_bytes = __builtin_amdgcn_readfirstlane((int)(plane * sizeof(float)));
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cost), 0, (int)cost_bytes, 0x00020000);
+  const unsigned ob = (unsigned)b * D * (unsigned)plane;
+  const int o00 = (int)((ob + y0 * w + x0) * 4u), o01 = (int)((ob + y0 * w + x1) * 4u);
+  const int o10 = (int)((ob + y1 * w + x0) * 4u), o11 = (int)((ob + y1 * w + x1) * 4u);
   float c[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) {
-    const float* p = cb + (size_t)d * plane;
-    const float v00 = p[(size_t)y0 * w + x0], v01 = p[(size_t)y0 * w + x1];
-    const float v10 = p[(size_t)y1 * w + x0], v11 = p[(size_t)y1 * w + x1];
+    const int so = d * plane_bytes;
+    const float v00 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, o00, so, 0));
+    const float v01 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, o01, so, 0));
+    const float v10 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, o10, so, 0));
+    const float v11 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, o11, so, 0));
     c[d] = hy0 * (wx0 * v00 + wx1 * v01) + hy1 * (wx0 * v10 + wx1 * v11);
   }
   // v_k = l0*c[i0] + l1*c[i1]; k is a compile-time constant after unrolling, so the
@@ -203,13 +212,14 @@ static int launch_tail(const float* cost, const float* disp_in, float* disp, flo
                        int w, int align_corners, hipStream_t s) {
   const size_t total = (size_t)B * 16 * h * w;
   const unsigned blocks = (unsigned)((total + 255) / 256);
-  if (D == 48) {
+  const size_t cost_bytes = (size_t)B * D * h * w * sizeof(float);
+  if (D == 48 && cost_bytes < 0x80000000ull) {          // 32-bit buffer offsets; larger volumes take the generic kernel
     if (align_corners)
       hipLaunchKernelGGL((upsample_softmax_regress_kernel<48, true>), dim3(blocks), dim3(256), 0, s, cost,
-                         disp_in, disp, unc, h, w, total);
+                         disp_in, disp, unc, h, w, total, (unsigned)cost_bytes);
     else
       hipLaunchKernelGGL((upsample_softmax_regress_kernel<48, false>), dim3(blocks), dim3(256), 0, s, cost,
-                         disp_in, disp, unc, h, w, total);
+                         disp_in, disp, unc, h, w, total, (unsigned)cost_bytes);
     return dv_launch_status();
   }
   const int threads = 64;

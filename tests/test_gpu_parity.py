@@ -107,6 +107,20 @@ def test_regression_tail_oracle_fullwidth():
     torch.testing.assert_close(unc.cpu(), O.disparity_uncertainty(disp_ref, prob), atol=2e-4, rtol=1e-5)
 
 
+def test_regression_tail_extreme_costs():
+    """Very peaked and very negative costs (softmax terms that underflow, a bin at -1e30): the compensated exp2 of the
+    tail kernel (csrc/dv_common.h: dv_exp_le0) must give the oracle's result, not NaN."""
+    g = _gen(8, "extreme")
+    cost = torch.randn(1, 1, 48, 6, 20, generator=g) * 30
+    cost[0, 0, 5] = -1e30
+    cost[0, 0, 17, 2] = 300.0
+    disp_ref, prob = O.upsample_softmax_regress(cost, 192)
+    disp, unc = S.upsample_softmax_regress(dev(cost))
+    assert bool(torch.isfinite(disp).all()) and bool(torch.isfinite(unc).all())
+    torch.testing.assert_close(disp.cpu(), disp_ref, atol=5e-4, rtol=1e-5)
+    torch.testing.assert_close(unc.cpu(), O.disparity_uncertainty(disp_ref, prob), atol=5e-4, rtol=1e-5)
+
+
 # ---------------------------------------------------------------- conv layers
 def _bn_tuple(sd, p):
     return (sd[p + ".weight"], sd[p + ".bias"], sd[p + ".running_mean"], sd[p + ".running_var"])

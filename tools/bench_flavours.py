@@ -136,10 +136,38 @@ def igev(b=4, h=96, w=312):
     return res
 
 
+def igev_model(b=4, h=384, w=1248, steps=20, iters=32):
+    """BASELINE config 5 on one GPU: the IGEVStereo_ddim drop-in module end to end (stub MobileNetV2 backbone: timm's
+    pretrained one does not exist offline), 1248x384, `steps` DDIM steps x `iters` GRU iterations, batch b."""
+    import types
+    import torch.nn.functional as F
+    from diffuvolume_amd.igev_stereo_ddim import Feature, IGEVStereo_ddim
+    from diffuvolume_amd.synth import StubMobileNetV2
+    args = types.SimpleNamespace(hidden_dims=[128, 128, 128], n_gru_layers=3, n_downsample=2, corr_levels=2, corr_radius=4,
+                                 slow_fast_gru=False, max_disp=192, mixed_precision=False)
+    cof = [0.5] + [0.0] * (steps - 1) + [0.5] if steps != 2 else None
+    m = IGEVStereo_ddim(args, feature=Feature(StubMobileNetV2()), sampling_timesteps=steps, ensemble_cof=cof)
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed=7, scale={"update_block.disp_head.conv2.weight": 0.05,
+                                                                      "update_block.disp_head.conv2.bias": 0.0,
+                                                                      "classifier.weight": 20.0}), strict=True)
+    m = m.to(DEV).eval()
+    g = _gen(77, "cfg5")
+    img1 = (torch.rand(b, 3, h, w, generator=g) * 255).to(DEV)
+    img2 = torch.roll(img1, -9, dims=-1)
+    flow_full = (9 + torch.randn(b, 1, h, w, generator=g)).clamp(0.5, 47).to(DEV)
+    flow_gt = F.interpolate(flow_full, size=(h // 4, w // 4), mode="bilinear") / 4
+    with torch.no_grad():
+        ms = timeit(lambda: m(img1, img2, flow_full, flow_gt, iters=iters, test_mode=True), warmup=1, steps=2)
+    return {"config": f"KITTI15 IGEVStereo_ddim B={b} {w}x{h}, {steps} DDIM steps x {iters} GRU iterations (stub backbone)",
+            "forward_ms": ms, "pairs_per_s": b / (ms / 1e3), "ms_per_gru_iteration": ms / (steps * iters)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pcw", action="store_true")
     ap.add_argument("--igev", action="store_true")
+    ap.add_argument("--igev-model", action="store_true", help="config 5: the whole IGEVStereo_ddim forward")
+    ap.add_argument("--ddim-steps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--no-ksplit", action="store_true", help="A/B: one block per output tile for the small launches too")
     a = ap.parse_args()
@@ -147,6 +175,10 @@ def main():
         from diffuvolume_amd import submodule as S
         S.Conv2dPlan.KSPLIT = False
     out = {}
+    if a.igev_model:
+        out["igev_model"] = igev_model(b=a.batch, steps=a.ddim_steps)
+        print(json.dumps(out, indent=1))
+        return
     if a.igev or not (a.pcw or a.igev):
         out["igev"] = igev(b=a.batch)
     if a.pcw or not (a.pcw or a.igev):

@@ -8,4 +8,7 @@ python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
 tail -c 300 gpurun_out/${T}_bench.err
 bash tools/profile_round.sh $T > gpurun_out/${T}_prof.log 2>&1
 tail -2 gpurun_out/${T}_prof.log
-python tools/trace_loop.py --parse gpurun_out/trace_$T > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace_$T -- python tools/trace_loop.py > /dev/null 2>&1
+python tools/trace_loop.py --parse gpurun_out/trace_$T > gpurun_out/${T}_loop_census.txt 2>&1
+rm -rf gpurun_out/trace_$T
+head -3 gpurun_out/${T}_loop_census.txt

@@ -181,6 +181,27 @@ def test_conv_oracle(cfg, precision):
         assert rel_err(out, torch.relu(y2 + res)) < 1e-5
 
 
+@pytest.mark.parametrize("cfg", [(5, (1, 3, 5, 7), False), (33, (2, 6, 9, 70), True), (32, (1, 4, 8, 130), False),
+                                 (1, (1, 1, 1, 1), False), (40, (1, 7, 3, 65), True)])
+def test_conv_single_channel_head_edges(cfg):
+    """The Cout == 1 classifier head (acv_ddim.py:214/:222) on its vector-ALU kernel (round 2: buffer-load staging,
+    double-buffered brick): channel counts that are not a multiple of anything, ragged D / H / W (tiles are
+    4 x 8 x 64), the volume * noise prologue and a residual."""
+    cin, dims, extras = cfg
+    g = _gen(23, str(cfg))
+    x = torch.randn(dims[0], cin, *dims[1:], generator=g)
+    w = torch.randn(1, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5
+    scale = torch.rand(dims[0], *dims[1:], generator=g) if extras else None
+    res = torch.randn(dims[0], 1, *dims[1:], generator=g) if extras else None
+    y = torch.nn.functional.conv3d(x if scale is None else x * scale.unsqueeze(1), w, None, 1, 1)
+    if res is not None:
+        y = torch.relu(y + res)
+    plan = S.Conv3dPlan(dev(w), None, stride=1, act=S.ACT_RELU if extras else S.ACT_NONE)
+    out = plan(dev(x), in_scale=None if scale is None else dev(scale), residual=None if res is None else dev(res))
+    assert out.shape == y.shape
+    assert float((out.cpu() - y).abs().max()) <= 1e-5 * max(1.0, float(y.abs().max()))
+
+
 @pytest.mark.parametrize("cfg", [(5, 20, (2, 5, 7, 19)), (3, 40, (1, 3, 3, 3)), (33, 33, (1, 1, 2, 17)),
                                  (4, 32, (1, 9, 5, 6)), (7, 70, (1, 2, 9, 33)), (12, 32, (1, 4, 4, 16))])
 def test_conv_winograd_edges(cfg):

@@ -91,3 +91,42 @@ def test_mis_sized_used_is_an_error_not_an_out_of_bounds_access(batch):
         model.ddim_sample(vol, batch["used"][:, ::4, ::4].contiguous(), x_T)
     with pytest.raises(RuntimeError):
         model.ddim_sample(vol, batch["used"], x_T[:, :24])
+
+
+def test_file_to_disparity_pipeline(tmp_path):
+    """PNG + PFM files on disk -> the reference's evaluation crop and normalisation -> origin ACVNet ->
+    ACVNet_DDIM -> metrics, and the same numbers as the tensor path on the same pixels."""
+    import numpy as np
+    from PIL import Image
+    from diffuvolume_amd import metrics as M
+    from diffuvolume_amd import pipeline as P
+    rng = np.random.default_rng(3)
+    h, w, d0 = 160, 288, 9                                   # a frame larger than the crop window used below
+    left = rng.integers(0, 255, (h, w, 3), dtype=np.uint8)
+    right = np.roll(left, -d0, axis=1)
+    disp = (d0 + rng.standard_normal((h, w))).astype(np.float32)
+    Image.fromarray(left).save(tmp_path / "l.png")
+    Image.fromarray(right).save(tmp_path / "r.png")
+    with open(tmp_path / "d.pfm", "wb") as f:                # PFM: bottom row first, negative scale = little endian
+        f.write(b"Pf\n%d %d\n-1.0\n" % (w, h))
+        f.write(disp[::-1].astype("<f4").tobytes())
+    sample = P.load_sceneflow_sample(str(tmp_path / "l.png"), str(tmp_path / "r.png"), str(tmp_path / "d.pfm"),
+                                     crop_w=256, crop_h=128)
+    assert sample["left"].shape == (1, 3, 128, 256) and sample["disparity"].shape == (1, 128, 256)
+    assert torch.equal(sample["disparity"][0], torch.from_numpy(disp[h - 128:, w - 256:].copy()))
+    origin = dv.ACVNet(192, False, False)
+    origin.load_state_dict(synth_state_dict(origin.state_dict(), seed=3, logit_gain=8.0), strict=True)
+    origin = origin.to(DEV)
+    ddim = _model(1)
+    torch.cuda.manual_seed(99)
+    scalars = P.test_sample(origin, ddim, sample, device=DEV)
+    assert set(scalars) == set(M.NAMES) and all(np.isfinite(v) for v in scalars.values())
+    # the same step written out on tensors
+    torch.cuda.manual_seed(99)
+    with torch.no_grad():
+        il, ir, gt = sample["left"].to(DEV), sample["right"].to(DEV), sample["disparity"].to(DEV)
+        used = origin(il, ir)[-1]
+        dn = torch.nn.functional.interpolate(torch.clamp(used, 0, 191).unsqueeze(1), size=(32, 64), mode="bilinear") / 4
+        pred = ddim(il, ir, used, dn, None)[0]
+        want = M.batch_metrics(pred, gt, (gt < 192) & (gt > 0))
+    assert scalars == {k: float(v) for k, v in want.items()}

@@ -440,8 +440,17 @@ def main():
         del ref
     if rank == 0 and world == 1 and not a.no_extras:
         out["extras"] = extras(a, sd, x, mask, device)
+    if world > 1:
+        torch.distributed.barrier()
     if rank == 0:
-        print(json.dumps(out))
+        # RCCL prints its version banner with printf (this image exports NCCL_DEBUG=VERSION): flush the C stdio buffer
+        # first so that the JSON line is the LAST line on stdout, whatever else the libraries wrote there
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 

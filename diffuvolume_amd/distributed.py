@@ -26,7 +26,10 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
             backend = os.environ.get("DV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
             torch.cuda.set_device(device_index(local))
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kwargs = {}
+        if backend == "nccl":       # bind the communicator to this rank's GPU (no "device unknown" barrier fallback)
+            kwargs["device_id"] = torch.device("cuda", device_index(local))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
     return rank, world, local
 
 

@@ -6,10 +6,12 @@
 //   out[b,c,d,y,x]   = p[b,d,y,x] * ref[b,c,y,x]                     c <  C
 //   out[b,C+c,d,y,x] = p[b,d,y,x] * (x>=d ? tgt[b,c,y,x-d] : 0)      c <  C
 //
-// Pure HBM write stream.  A block owns one (b, y) row and a chunk of 8 channels of
-// both halves.  Lane <-> 4 consecutive x (16-byte stores, contiguous along W),
-// wave <-> blocks of 4 disparities.  The shifted target comes from LDS (row staged
-// once behind a zero pad) with two ds_read_b128 per 4x4 register tile.
+// Pure HBM write stream.  A block owns FOUR consecutive rows (b, y0..y0+3) and a chunk of 8 channels of both
+// halves; wave <-> one of the rows, lane <-> 4 consecutive x (16-byte stores, contiguous along W), so that the four
+// waves of a block write a contiguous 4-row slab (3.8 KB at W = 240) of every (channel, disparity) plane at about
+// the same time (round 1 had one row per block, waves on different disparities: 960-byte bursts scattered 122 KB
+// apart, 3.6 TB/s) and every wave computes the softmax normaliser of its own row only.  The shifted target comes
+// from LDS (rows staged once behind a zero pad) with two ds_read_b128 per 4x4 register tile.
 #include "dv_common.h"
 
 namespace {
@@ -32,22 +34,27 @@ __global__ __launch_bounds__(256) void concat_rows_kernel(const float* __restric
   float4* rows = reinterpret_cast<float4*>(smem);
 
   const int nchunks = (C + kChunk - 1) / kChunk;
+  const int nyt = (H + 3) >> 2;
   const int cchunk = blockIdx.x % nchunks;
   const int by = blockIdx.x / nchunks;
-  const int y = by % H;
-  const int b = by / H;
+  const int y0 = (by % nyt) * 4;
+  const int b = by / nyt;
   const int c0 = cchunk * kChunk;
   const int nc = min(kChunk, C - c0);
   const size_t plane = (size_t)H * W;
 
-  for (int i = threadIdx.x; i < nc * rowq; i += blockDim.x) {
-    const int c = i / rowq, q = i - c * rowq;
+  for (int i = threadIdx.x; i < 4 * nc * rowq; i += blockDim.x) {      // rows[(row * nc + c) * rowq + q]
+    const int rc = i / rowq, q = i - rc * rowq;
+    const int rw = rc / nc, c = rc - rw * nc;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (q >= padq)
-      v = reinterpret_cast<const float4*>(tgt + ((size_t)b * C + c0 + c) * plane + (size_t)y * W)[q - padq];
+    if (q >= padq && y0 + rw < H)
+      v = reinterpret_cast<const float4*>(tgt + ((size_t)b * C + c0 + c) * plane + (size_t)(y0 + rw) * W)[q - padq];
     rows[i] = v;
   }
   __syncthreads();
+  const int y = y0 + wave;
+  if (y >= H) return;
+  rows += (size_t)wave * nc * rowq;
 
   const size_t vstride = (size_t)D * plane;  // channel stride of the volume
   const float* attrow = ATT ? att + (size_t)b * D * plane + (size_t)y * W : nullptr;
@@ -62,23 +69,25 @@ __global__ __launch_bounds__(256) void concat_rows_kernel(const float* __restric
         const float4 a = reinterpret_cast<const float4*>(attrow + (size_t)d * plane)[t];
         mx.x = fmaxf(mx.x, a.x); mx.y = fmaxf(mx.y, a.y); mx.z = fmaxf(mx.z, a.z); mx.w = fmaxf(mx.w, a.w);
       }
+      // exp(a - max) on the compensated exp2 of dv_common.h (~1 ulp, like expf); the softmax is then one reciprocal
+      // per pixel, p_d = e_d * (1/sum): at most one ulp of p_d from e_d / sum
       float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int d = 0; d < D; ++d) {
         const float4 a = reinterpret_cast<const float4*>(attrow + (size_t)d * plane)[t];
-        sum.x += expf(a.x - mx.x); sum.y += expf(a.y - mx.y);
-        sum.z += expf(a.z - mx.z); sum.w += expf(a.w - mx.w);
+        sum.x += dv_exp_le0(a.x - mx.x); sum.y += dv_exp_le0(a.y - mx.y);
+        sum.z += dv_exp_le0(a.z - mx.z); sum.w += dv_exp_le0(a.w - mx.w);
       }
-      rs = sum;
+      rs = make_float4(1.f / sum.x, 1.f / sum.y, 1.f / sum.z, 1.f / sum.w);
     }
-    for (int e = wave; e < eblocks; e += 4) {
+    for (int e = 0; e < eblocks; ++e) {
       float p[4][4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int d = 4 * e + r;
         if (ATT && d < D) {
           const float4 a = reinterpret_cast<const float4*>(attrow + (size_t)d * plane)[t];
-          p[r][0] = expf(a.x - mx.x) / rs.x; p[r][1] = expf(a.y - mx.y) / rs.y;
-          p[r][2] = expf(a.z - mx.z) / rs.z; p[r][3] = expf(a.w - mx.w) / rs.w;
+          p[r][0] = dv_exp_le0(a.x - mx.x) * rs.x; p[r][1] = dv_exp_le0(a.y - mx.y) * rs.y;
+          p[r][2] = dv_exp_le0(a.z - mx.z) * rs.z; p[r][3] = dv_exp_le0(a.w - mx.w) * rs.w;
         } else {
           p[r][0] = p[r][1] = p[r][2] = p[r][3] = 1.f;
         }
@@ -152,10 +161,10 @@ int launch(const float* ref, const float* tgt, const float* att, float* out, int
   const bool fast = (W % 4 == 0) && dv_aligned16(ref) && dv_aligned16(tgt) && dv_aligned16(out) &&
                     (!ATT || dv_aligned16(att));
   const int rowq = ((D + 3) / 4 + 1) + W / 4;
-  const size_t lds = (size_t)kChunk * rowq * sizeof(float4);
+  const size_t lds = (size_t)4 * kChunk * rowq * sizeof(float4);
   if (fast && lds <= 64 * 1024) {
     const int nchunks = (C + kChunk - 1) / kChunk;
-    hipLaunchKernelGGL((concat_rows_kernel<ATT, ZL>), dim3(B * H * nchunks), dim3(256), lds, s, ref,
+    hipLaunchKernelGGL((concat_rows_kernel<ATT, ZL>), dim3(B * ((H + 3) / 4) * nchunks), dim3(256), lds, s, ref,
                        tgt, att, out, C, H, W, D);
   } else {
     const size_t total = (size_t)B * 2 * C * D * H * W;

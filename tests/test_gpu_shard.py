@@ -55,7 +55,9 @@ def test_two_process_shards_match_single_process():
     full, _ = W.shard_epe(model, x, gt, 0, 8, dev, acc8)
     assert full[:4].double().sum().item().hex() == sums[0][0] and full[4:].double().sum().item().hex() == sums[1][0]
     epe8 = acc8.reduce()["EPE"]
-    assert abs(epe8 - single["EPE"]) < 1e-12                        # mean of 8 == mean of two means of 4
+    # mean of 8 == mean of two means of 4, up to the float32 rounding of the per-batch means (the reference's metric
+    # functions return float32 scalars, utils/metrics.py:22-40)
+    assert abs(epe8 - single["EPE"]) < 4e-6 * max(1.0, abs(epe8))
 
 
 @pytest.mark.timeout(900)

@@ -5,12 +5,11 @@ reference's class API (KITTI15/core/geometry_ddim.py:6-80).
 then ``corr_fn(disp, coords, noisy) -> [B, 162, h, w]`` once per GRU iteration.  The lookup,
 the `geo_volume * noise` multiply and both level-1 poolings are one HIP kernel
 (``dv_geo_filter_lookup_f32``); the all-pairs correlation of ``__init__`` (one GEMM per image
-row, once per pair) is a plain library GEMM via ``torch.einsum``.
+row, once per pair) and its pooled level are a second one (``dv_allpairs_corr_f32``).
 """
 from __future__ import annotations
 
 import torch
-import torch.nn.functional as F
 
 from . import _lib
 from .profiling import timed
@@ -25,10 +24,7 @@ class Combined_Geo_Encoding_Volume:
         self.geo_volume = _dev_f32(geo_volume, "geo_volume")                 # [B,C,D,h,w], no permuted copy
         b, c, d, h, w = self.geo_volume.shape
         self.channel = c
-        corr = self.corr(_dev_f32(init_fmap1, "init_fmap1"), _dev_f32(init_fmap2, "init_fmap2"))
-        w2 = corr.shape[-1]
-        self.corr0 = corr.reshape(b, h, w, w2).contiguous()
-        self.corr1 = F.avg_pool2d(corr.reshape(b * h * w, 1, 1, w2), [1, 2], stride=[1, 2]).reshape(b, h, w, w2 // 2).contiguous()
+        self.corr0, self.corr1 = self._corr_levels(_dev_f32(init_fmap1, "init_fmap1"), _dev_f32(init_fmap2, "init_fmap2"))
 
     def __call__(self, disp, coords, noisy):
         disp = _dev_f32(disp, "disp")
@@ -49,9 +45,26 @@ class Combined_Geo_Encoding_Volume:
         return out
 
     @staticmethod
+    def _corr_levels(fmap1, fmap2):
+        """corr0 [B,H,W1,W2] and its avg_pool2d([1,2]) level corr1 [B,H,W1,W2//2] in one launch."""
+        B, C, H, W1 = fmap1.shape
+        if fmap2.shape[:3] != fmap1.shape[:3]:
+            raise RuntimeError(f"feature maps must agree in batch, channels and height: {tuple(fmap1.shape)} vs {tuple(fmap2.shape)}")
+        W2 = fmap2.shape[-1]
+        corr0 = torch.empty((B, H, W1, W2), dtype=torch.float32, device=fmap1.device)
+        corr1 = torch.empty((B, H, W1, W2 // 2), dtype=torch.float32, device=fmap1.device)
+        lib = _lib.load()
+        with torch.cuda.device(fmap1.device):
+            timed("allpairs_corr", 2.0 * B * H * W1 * W2 * C, 4.0 * (fmap1.numel() + fmap2.numel() + corr0.numel() + corr1.numel()),
+                  lambda: _lib.check(lib.dv_allpairs_corr_f32(fmap1.data_ptr(), fmap2.data_ptr(), corr0.data_ptr(),
+                                                              corr1.data_ptr(), B, C, H, W1, W2, _lib.stream_ptr()),
+                                     "dv_allpairs_corr_f32"))
+        return corr0, corr1
+
+    @staticmethod
     def corr(fmap1, fmap2):
         """All-pairs correlation along the epipolar line (geometry_ddim.py:72-80): [B,H,W1,1,W2]."""
-        B, D, H, W1 = fmap1.shape
-        W2 = fmap2.shape[-1]
-        corr = torch.einsum("aijk,aijh->ajkh", fmap1, fmap2)
-        return corr.reshape(B, H, W1, 1, W2).contiguous()
+        fmap1, fmap2 = _dev_f32(fmap1, "fmap1"), _dev_f32(fmap2, "fmap2")
+        corr0, _ = Combined_Geo_Encoding_Volume._corr_levels(fmap1, fmap2)
+        B, H, W1, W2 = corr0.shape
+        return corr0.reshape(B, H, W1, 1, W2)

@@ -303,6 +303,14 @@ int dv_ddim_step(const float* disp, const float* unc, const float* used, const f
 int dv_context_upsample_f32(const float* disp_low, const float* weights, float* out, int B, int h, int w,
                             float scale, int apply_softmax, dv_stream_t stream);
 
+/* ---- IGEV: all-pairs correlation along the epipolar line + its level-1 pooling --------
+ * Combined_Geo_Encoding_Volume.corr (KITTI15/core/geometry_ddim.py:72-80: einsum 'aijk,aijh->ajkh') and the
+ * avg_pool2d([1,2]) of the pyramid (:28-30), once per stereo pair:
+ *   corr0[b,y,x1,x2] = sum_c fmap1[b,c,y,x1] * fmap2[b,c,y,x2];   corr1[b,y,x1,x] = (corr0[..,2x] + corr0[..,2x+1]) / 2
+ * fmap1 [B,C,H,W1], fmap2 [B,C,H,W2] (C <= 256); corr0 [B,H,W1,W2]; corr1 [B,H,W1,W2/2] (floor). */
+int dv_allpairs_corr_f32(const float* fmap1, const float* fmap2, float* corr0, float* corr1, int B, int C, int H,
+                         int W1, int W2, dv_stream_t stream);
+
 /* ---- IGEV: geometry-encoding-volume lookup with the noise filter -----------------------
  * Combined_Geo_Encoding_Volume.__call__ (KITTI15/core/geometry_ddim.py:33-69), 2 pyramid levels,
  * radius 4: per pixel, (geo[c,:] * noise[:]) linearly sampled at disp/2^i + {-4..4} plus the all-pairs

@@ -523,7 +523,7 @@ def test_igev_geo_filter_lookup_golden():
     fn = Combined_Geo_Encoding_Volume(dev(g["f1"]), dev(g["f2"]), dev(g["geo"]), num_levels=2, radius=4)
     out = fn(dev(g["disp"]), dev(g["coords"]), dev(g["noisy"]))
     assert out.shape == g["out"].shape
-    torch.testing.assert_close(out.cpu(), g["out"], atol=2e-5, rtol=1e-5)   # corr GEMM order differs (rocBLAS)
+    torch.testing.assert_close(out.cpu(), g["out"], atol=2e-5, rtol=1e-5)   # the corr GEMM sums channels in another order
 
 
 def test_igev_geo_filter_lookup_oracle_kitti_size():
@@ -539,6 +539,30 @@ def test_igev_geo_filter_lookup_oracle_kitti_size():
     ref = IO.geo_filter_lookup(geo, f1, f2, disp, coords, noisy)
     out = Combined_Geo_Encoding_Volume(dev(f1), dev(f2), dev(geo))(dev(disp), dev(coords), dev(noisy))
     torch.testing.assert_close(out.cpu(), ref, atol=3e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(1, 24, 3, 78, 78), (2, 96, 2, 40, 40), (1, 7, 2, 17, 33), (1, 130, 1, 16, 21),
+                                   (1, 4, 1, 5, 2)])
+def test_igev_allpairs_corr_oracle(shape):
+    """corr() and its pooled level (geometry_ddim.py:72-80, :28-30) on the MFMA kernel vs the oracle's einsum:
+    ragged W1 / W2 (partial 16-wide tiles, odd W2: the pooled level drops the last column), C not a multiple of 4."""
+    from diffuvolume_amd.geometry_ddim import Combined_Geo_Encoding_Volume as G
+    from oracle import igev_oracle as IO
+    b, c, h, w1, w2 = shape
+    gen = _gen(63, str(shape))
+    f1, f2 = torch.randn(b, c, h, w1, generator=gen), torch.randn(b, c, h, w2, generator=gen)
+    ref = IO.all_pairs_corr(f1.double(), f2.double())                          # [b,h,w1,w2]
+    ref1 = torch.nn.functional.avg_pool2d(ref.reshape(b * h * w1, 1, 1, w2), [1, 2], stride=[1, 2]).reshape(b, h, w1, w2 // 2)
+    c0, c1 = G._corr_levels(dev(f1), dev(f2))
+    assert c0.shape == (b, h, w1, w2) and c1.shape == (b, h, w1, w2 // 2)
+    bar = 2e-6 * float(ref.abs().max())
+    assert float((c0.cpu().double() - ref).abs().max()) <= bar
+    assert float((c1.cpu().double() - ref1).abs().max()) <= bar
+    full = G.corr(dev(f1), dev(f2))                                            # the reference's static method
+    assert full.shape == (b, h, w1, 1, w2) and torch.equal(full.reshape(b, h, w1, w2), c0)
+    # pooled level formed from the accumulators == pooling the stored level
+    pooled = torch.nn.functional.avg_pool2d(c0.reshape(b * h * w1, 1, 1, w2), [1, 2], stride=[1, 2]).reshape(b, h, w1, w2 // 2)
+    assert torch.equal(pooled, c1)
 
 
 # ---------------------------------------------------------------- split-fp16 (hi/lo) MFMA convolution

@@ -25,21 +25,38 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+constexpr int round_up_mod64_32(int v) {   // smallest v' >= v with v' % 64 == 32
+  const int r = v % 64;
+  return r <= 32 ? v + (32 - r) : v + (64 - r) + 32;
+}
+
 // MTW = M-tiles (planes) per wave: 1 -> 4 planes per block, 128 accumulator registers, two blocks per CU;
 // 2 -> 8 planes per block (wave w owns planes w and w+4), 256 accumulator registers (the AGPR half of the
 // 512-register file), one block per CU: every B fragment feeds two MFMAs, half the weight DMA / barriers / blocks.
-template <int MTW_>
+// SHAPE = how the 16 Winograd tiles of a wave's M index lie in its plane: 0 -> 2 tile rows x 8 tile columns
+// (4 x 16 outputs), 1 -> 4 x 4 (8 x 8 outputs), 2 -> 8 x 2 (16 x 4 outputs).  The host picks the shape that pads
+// the plane least: a 120-wide plane is 7.5 tiles of 16 but exactly 15 tiles of 8.
+template <int MTW_, int SHAPE_ = 0>
 struct WG {
-  static constexpr int MTW = MTW_;
-  static constexpr int KC = 4, NT = 2, TD = 4 * MTW, TH = 4, TW = 16;
+  static constexpr int MTW = MTW_, SHAPE = SHAPE_;
+  static constexpr int TR = SHAPE == 0 ? 2 : (SHAPE == 1 ? 4 : 8), TC = 16 / TR;     // tile rows / columns per wave
+  static constexpr int KC = 4, NT = 2, TD = 4 * MTW, TH = 2 * TR, TW = 2 * TC;
   static constexpr int IZ = TD + 2, IY = TH + 2, IX = TW + 2;
-  static constexpr int PRAW = IZ * IY * IX;          // raw positions per channel (648 / 1080)
-  // raw brick [c][z][y][RX]: row stride 24 and a channel stride = 32 mod 64 put the 16 tiles x 2 channels a 32-lane
-  // half reads with one ds_read_b64 (tile columns 2 floats apart, tile rows 2*RX = 48 apart) on 64 distinct banks
-  static constexpr int RX = 24;
-  static constexpr int RAWP = IZ * IY * RX;
+  static constexpr int PRAW = IZ * IY * IX;          // raw positions per channel (648 / 600 / 648)
+  // raw brick [c][z][y][RX].  Bank plan of the patch reads: a 32-lane half of a ds_read_b64 holds 16 tiles x 2
+  // channels; with a channel stride = 32 mod 64 the two channels take disjoint halves of the 64 banks, and inside a
+  // half the tile columns (2 floats apart) and tile rows (2*RX apart) have to tile 32 banks without overlap:
+  //   2 x 8: columns cover 16 banks, 2*RX = 48 puts the second tile row on the other 16
+  //   4 x 4: columns cover 8 banks, 2*RX = 24 -> rows at 0, 24, 48, 72 = 8 (mod 64)
+  //   8 x 2: columns cover 4 banks, 2*RX = 12 -> rows at 0, 12, 24, 36, 48, 60, 8, 20 (mod 64)
+  static constexpr int RX = SHAPE == 0 ? 24 : (SHAPE == 1 ? 12 : 6);
+  static constexpr int RAWP = round_up_mod64_32(IZ * IY * RX);
   static constexpr int RAW_FLOATS = KC * RAWP;
   static constexpr int NS = (PRAW + 255) / 256;
+  // where the staging lanes past the brick put their (zero) value: a padding column of row 0, else the channel tail
+  static constexpr int DUMP = RX > IX ? IX : IZ * IY * RX;
+  static_assert(RX >= IX && RX % 2 == 0, "row stride");
+  static_assert(DUMP < RAWP, "the dump float lies inside the channel");
   static_assert(RAWP % 64 == 32, "bank plan of the patch reads");
 };
 namespace wg {
@@ -60,9 +77,9 @@ struct WinoArgs {
   int fast_ok;           // W % 4 == 0, 16-byte aligned pointers
 };
 
-template <bool HAS_SCALE, int MTW>
+template <bool HAS_SCALE, int MTW, int SHAPE = 0>
 __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(WinoArgs a) {
-  using G = WG<MTW>;
+  using G = WG<MTW, SHAPE>;
   constexpr int KC = G::KC, NT = G::NT, TD = G::TD, TH = G::TH, TW = G::TW, IY = G::IY, IX = G::IX, PRAW = G::PRAW;
   constexpr int RX = G::RX, RAWP = G::RAWP, RAW_FLOATS = G::RAW_FLOATS, NS = G::NS, U_CHUNK = wg::U_CHUNK;
   static_assert((2 * U_CHUNK + 2 * RAW_FLOATS) * 4 * (MTW == 1 ? 2 : 1) <= 160 * 1024, "LDS budget");
@@ -113,7 +130,7 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
                     (unsigned)x < (unsigned)a.W;
     const unsigned sp = ok ? (unsigned)((z * a.H + y) * a.W + x) : 0u;
     sob[i] = ok ? sp * 4u : 0x80000000u;
-    lro[i] = r < PRAW ? (zz * IY + yy) * RX + xx : IX;      // lanes past the brick write a column no patch reads
+    lro[i] = r < PRAW ? (zz * IY + yy) * RX + xx : G::DUMP;   // lanes past the brick write a float no patch reads
     if (HAS_SCALE) scl[i] = (ok && scb) ? scb[sp] : 1.f;
   }
   const int vol_bytes = __builtin_amdgcn_readfirstlane((int)(vol * sizeof(float)));   // < 2^31 (checked by the host)
@@ -159,10 +176,13 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
     }
   };
 
-  // this lane's 4x4 patch: tile (row j&1, column j>>1) of plane wave+kd, channel kq;  B rows (kq, j)
+  // this lane's 4x4 patch: M index j = tile (row 2*grow + (j&1), column 2*gcol + ((j>>1)&1)) with the 2x2-tile group
+  // j>>2 laid out per SHAPE, of plane wave+kd, channel kq;  B rows (kq, j)
+  constexpr int GC = G::TC / 2;                       // groups per row of groups: 4 / 2 / 1
+  const int p_tr = 2 * ((j >> 2) / GC) + (j & 1), p_tc = 2 * ((j >> 2) % GC) + ((j >> 1) & 1);
   int patch_lo[MTW];
 #pragma unroll
-  for (int mt = 0; mt < MTW; ++mt) patch_lo[mt] = kq * RAWP + ((wave + 4 * mt) * IY + 2 * (j & 1)) * RX + 2 * (j >> 1);
+  for (int mt = 0; mt < MTW; ++mt) patch_lo[mt] = kq * RAWP + ((wave + 4 * mt) * IY + 2 * p_tr) * RX + 2 * p_tc;
   int b_lo[4];
 #pragma unroll
   for (int p4 = 0; p4 < 4; ++p4) b_lo[p4] = (kq * 16 + j) * 16 + ((p4 ^ ((j >> 2) & 3)) * 4);
@@ -284,7 +304,8 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
   // ---- epilogue: Y = At M A per tile, BN scale/bias, residual, activation.  M index m = tile (row m&1, column
   // m>>1), so a lane (cout j, tiles 4*kq .. 4*kq+3) holds tile columns 2kq, 2kq+1 of both tile rows: 4 consecutive x
   // of four output rows, and the four kq lanes of a channel write 64 contiguous bytes per row ----
-  const int xb = x0 + 4 * kq;
+  // accumulator rows 4kq..4kq+3 = the 2x2 tiles of group kq = a 4 x 4 output patch at (4*(kq/GC), 4*(kq%GC))
+  const int xb = x0 + 4 * (kq % GC), yq = 4 * (kq / GC);
   const bool fast = a.fast_ok && x0 + TW <= a.W && y0 + TH <= a.H;
   const float slope = a.act == DV_ACT_RELU ? 0.f : (a.act == DV_ACT_LEAKY ? 0.01f : 1.f);
   const bool mish = a.act == DV_ACT_MISH;
@@ -298,7 +319,7 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
     if (co >= a.Cout) continue;
     const float sc = a.ch_scale ? a.ch_scale[co] : 1.f;
     const float bi = a.ch_bias ? a.ch_bias[co] : 0.f;
-    const size_t cbase = (((size_t)b * a.Cout + co) * a.D + zo) * plane + (size_t)y0 * a.W + xb;
+    const size_t cbase = (((size_t)b * a.Cout + co) * a.D + zo) * plane + (size_t)(y0 + yq) * a.W + xb;
     f32x4 rv[4];
     if (fast && a.residual) {
 #pragma unroll
@@ -334,7 +355,7 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = mish ? dv_act(v[e], DV_ACT_MISH) : fmaxf(v[e], v[e] * slope);
           *reinterpret_cast<f32x4*>(a.out + o) = v;
-        } else if (y0 + yr < a.H) {
+        } else if (y0 + yq + yr < a.H) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (xb + e < a.W) {
@@ -421,19 +442,32 @@ extern "C" int dv_conv3d_wino_f32(const float* in, const float* wpacked, const f
   a.B = B; a.Cin = Cin; a.D = D; a.H = H; a.W = W; a.Cout = Cout; a.act = act;
   a.fast_ok = (W % 4 == 0) && dv_aligned16(out) && (!residual || dv_aligned16(residual));
   hipStream_t s = (hipStream_t)stream;
-  auto launch = [&](auto mtw) {
-    constexpr int MTW = decltype(mtw)::value;
-    using G = WG<MTW>;
+  auto launch = [&](auto mtw, auto shape) {
+    constexpr int MTW = decltype(mtw)::value, SHAPE = decltype(shape)::value;
+    using G = WG<MTW, SHAPE>;
     a.ntx = cdiv(W, G::TW); a.nty = cdiv(H, G::TH); a.ntz = cdiv(D, G::TD); a.nco = cdiv(Cout, 32);
     const long long blocks = (long long)B * a.nco * a.ntz * a.nty * a.ntx;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return (int)DV_ERR_SHAPE;
     if (in_scale)
-      hipLaunchKernelGGL((conv3d_wino_kernel<true, MTW>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((conv3d_wino_kernel<true, MTW, SHAPE>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     else
-      hipLaunchKernelGGL((conv3d_wino_kernel<false, MTW>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((conv3d_wino_kernel<false, MTW, SHAPE>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     return dv_launch_status();
   };
+  // tile shape of a wave's 16 Winograd tiles: the one that pads the plane least (16 x 4, 8 x 8 or 4 x 16 outputs);
+  // ties go to the widest, whose rows are stored in 64-byte runs
+  auto padded = [&](int tw, int th) { return (long long)cdiv(W, tw) * tw * cdiv(H, th) * th; };
+  const long long p0 = padded(16, 4), p1 = padded(8, 8), p2 = padded(4, 16);
+  int shape = 0;
+  if (p1 < p0 && p1 <= p2) shape = 1;
+  else if (p2 < p0 && p2 < p1) shape = 2;
+#ifdef DV_WINO_FORCE_SHAPE
+  shape = DV_WINO_FORCE_SHAPE;
+#endif
   // MTW = 2 (one wave per SIMD on the 512-register file, two planes per wave) is correct but measured 4.25 vs 3.09 ms
   // on the 32->32 layer: with a single wave per SIMD the LDS / barrier latencies of every chunk are exposed.
-  return launch(std::integral_constant<int, 1>{});
+  using one = std::integral_constant<int, 1>;
+  if (shape == 1) return launch(one{}, std::integral_constant<int, 1>{});
+  if (shape == 2) return launch(one{}, std::integral_constant<int, 2>{});
+  return launch(one{}, std::integral_constant<int, 0>{});
 }

@@ -203,7 +203,11 @@ def test_conv_single_channel_head_edges(cfg):
 
 
 @pytest.mark.parametrize("cfg", [(5, 20, (2, 5, 7, 19)), (3, 40, (1, 3, 3, 3)), (33, 33, (1, 1, 2, 17)),
-                                 (4, 32, (1, 9, 5, 6)), (7, 70, (1, 2, 9, 33)), (12, 32, (1, 4, 4, 16))])
+                                 (4, 32, (1, 9, 5, 6)), (7, 70, (1, 2, 9, 33)), (12, 32, (1, 4, 4, 16)),
+                                 # planes that select each tile shape of a wave's 16 Winograd tiles (least padding wins):
+                                 # 8x8 outputs exact / ragged, 16x4 outputs exact / ragged, 4x16 outputs ragged
+                                 (8, 32, (1, 5, 8, 120)), (6, 20, (2, 3, 7, 37)), (8, 64, (1, 4, 16, 60)),
+                                 (5, 32, (1, 6, 30, 10)), (4, 16, (1, 3, 19, 9))])
 def test_conv_winograd_edges(cfg):
     """Winograd kernel on shapes that leave every kind of partial tile: odd H / W (half 2x2 output tiles), depth not a
     multiple of the 4 planes of a block, channel tails on both sides (Cin % 4, Cout % 32), rows that are not

@@ -40,13 +40,19 @@ ALGO_BYTES_PER_PAIR = 23.2e9      # ideal-fusion fp32 HBM bytes of 
 ALGO_FLOP_PER_PAIR = 3.76e12
 
 
-DOMINANT_KERNEL = "conv3d_wino_kernel<false, 1>"
+# Dominant kernel = one rocprofv3 kernel name: the Winograd instantiation the 32->32 layers run (no filter prologue,
+# one plane per wave, 2 x 8 tiles per wave): 20 launches per DDIM step, a third of the step.
+DOMINANT_KERNEL = "conv3d_wino_kernel<false, 1, 0>"
+DOMINANT_TAGS = ("conv3d_k3s1_co32",)
 WINO_MULT_REDUCTION = 2.25        # F(2x2,3x3) in-plane: 16 multiplies per 2x2 outputs and depth tap instead of 36
-# the next kernels by time: (KernelTimer tags, rocprofv3 kernel name, issued-flop divisor)
+# the next kernels by time: (KernelTimer tags, rocprofv3 kernel name, issued-flop divisor).  The 64- and 128-channel
+# layers run the 4 x 4- and 8 x 2-tile instantiations of the same template (120- and 60-wide planes, no padding).
 SIDE_KERNELS = [
     (("deconv3d_k3s2_redir",), "deconv3d_mfma_kernel<3, 8>", 1.0),
     (("conv3d_k3s2_co64", "conv3d_k3s2_co128"), "conv3d_mfma_kernel<Geo<3, 2, 4, 2, 4, 2, 4, 2>, true>", 1.0),
-    (("conv3d_k3s1_co32_filter",), "conv3d_wino_kernel<true, 1>", WINO_MULT_REDUCTION),
+    (("conv3d_k3s1_co32_filter",), "conv3d_wino_kernel<true, 1, 0>", WINO_MULT_REDUCTION),
+    (("conv3d_k3s1_co64",), "conv3d_wino_kernel<false, 1, 1>", WINO_MULT_REDUCTION),
+    (("conv3d_k3s1_co128",), "conv3d_wino_kernel<false, 1, 2>", WINO_MULT_REDUCTION),
 ]
 
 
@@ -383,10 +389,9 @@ def main():
     }
     if rank == 0 and timer is not None:
         ks = timer.summary()
-        # dominant kernel = conv3d_wino_kernel<false>: every 3x3x3 stride-1 layer without the noise prologue
-        # (32->32, 64->64, 128->128; the filter layer is the <true> instantiation).  All its launches are pooled so
-        # that `avg_ms` is the same average rocprofv3 --stats reports for that kernel name.
-        fam = {k: v for k, v in ks.items() if k in ("conv3d_k3s1_co32", "conv3d_k3s1_co64", "conv3d_k3s1_co128")}
+        # dominant kernel: `avg_ms` is the average rocprofv3 --stats reports for that kernel name in the same command
+        fam = {k: v for k, v in ks.items() if k in DOMINANT_TAGS}
+        allw = {k: v for k, v in ks.items() if k in ("conv3d_k3s1_co32", "conv3d_k3s1_co64", "conv3d_k3s1_co128")}
         if fam:
             flops = sum(v["flops"] for v in fam.values())
             ms = sum(v["total_ms"] for v in fam.values())
@@ -403,16 +408,15 @@ def main():
                                "algorithmic_tflops": algo, "multiply_reduction": WINO_MULT_REDUCTION,
                                "algorithmic_bytes_per_launch": algo_bytes,
                                "traffic_over_algorithmic": None if traffic is None else traffic / algo_bytes,
-                               "kernel": DOMINANT_KERNEL + " (all 3x3x3 stride-1 layers of dres0/dres1/hourglass/classif2 "
-                                         "except the filter layer; Winograd F(2x2,3x3) in-plane, depth taps direct, "
+                               "kernel": DOMINANT_KERNEL + " (the 32->32 3x3x3 stride-1 layers of dres0/dres1/hourglass/"
+                                         "classif2 at 48x128x240; Winograd F(2x2,3x3) in-plane, depth taps direct, "
                                          "v_mfma_f32_16x16x4_f32)",
                                "launches": launches, "avg_ms": ms / launches,
                                "algorithmic_gflop_per_launch": flops / launches / 1e9,
-                               "by_layer": {k: {"launches": v["launches"], "avg_ms": v["avg_ms"],
-                                                "algorithmic_tflops": v["flops"] / v["total_ms"] / 1e9,
-                                                "issued_frac": v["flops"] / v["total_ms"] / 1e9 / WINO_MULT_REDUCTION
-                                                               / PEAK_MFMA_F32_TFLOPS}
-                                            for k, v in sorted(fam.items())}}
+                               # every instantiation of the template without the filter prologue (32 / 64 / 128 channels)
+                               "all_shapes_issued_frac": sum(v["flops"] for v in allw.values())
+                                                         / sum(v["total_ms"] for v in allw.values()) / 1e9
+                                                         / WINO_MULT_REDUCTION / PEAK_MFMA_F32_TFLOPS}
         side = []
         for tags, kname, div in SIDE_KERNELS:
             sel = [ks[t] for t in tags if t in ks]

@@ -78,7 +78,9 @@ __global__ __launch_bounds__(256, G::WPS) void conv3d_mfma_kernel(ConvArgs a) {
   const int j = lane & 15, kq = lane >> 4;
 
   // block -> (b, co-slice, z, y, x) tile; consecutive tiles on one XCD share halos in its L2
+  // (the output-channel slices of a tile are neighbours in the linear order: same XCD, same time, one HBM read of the brick)
   unsigned t = dv_xcd_remap(blockIdx.x, gridDim.x);
+  const int tc = t % a.nco; t /= a.nco;
   int tx, ty, tz;
   if (a.order == 1) {
     tz = t % a.ntz; t /= a.ntz;
@@ -93,8 +95,7 @@ __global__ __launch_bounds__(256, G::WPS) void conv3d_mfma_kernel(ConvArgs a) {
     ty = t % a.nty; t /= a.nty;
     tz = t % a.ntz; t /= a.ntz;
   }
-  const int tc = t % a.nco;
-  const int b = t / a.nco;
+  const int b = t;
   const int x0 = tx * G::TW, y0 = ty * G::TH, z0 = tz * G::TD, co0 = tc * G::COUT;
   const int xi0 = x0 * G::S - G::PAD, yi0 = y0 * G::S - G::PAD, zi0 = z0 * G::S - G::PAD;
 

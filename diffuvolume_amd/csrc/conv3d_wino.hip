@@ -92,12 +92,14 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;
 
+  // the output-channel slices of a tile are neighbours in the linear order: they run at the same time on the same XCD
+  // (dv_xcd_remap), so the input brick they all read comes from HBM once and from that XCD's L2 for the others
   unsigned t = dv_xcd_remap(blockIdx.x, gridDim.x);
+  const int tc = t % a.nco; t /= a.nco;
   const int tx = t % a.ntx; t /= a.ntx;
   const int ty = t % a.nty; t /= a.nty;
-  const int tz = t % a.ntz; t /= a.ntz;
-  const int tc = t % a.nco;
-  const int b = t / a.nco;
+  const int tz = t % a.ntz;
+  const int b = t / a.ntz;
   const int x0 = tx * TW, y0 = ty * TH, z0 = tz * TD, co0 = tc * 32;
 
   f32x4 acc[MTW][16][NT];

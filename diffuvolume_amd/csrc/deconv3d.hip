@@ -83,12 +83,13 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: row bases below stay in SGPRs
   const int j = lane & 15, kq = lane >> 4;
 
+  // (the output-channel slices of a tile are neighbours in the linear order: same XCD, same time, one HBM read of the brick)
   unsigned t = dv_xcd_remap(blockIdx.x, gridDim.x);
+  const int tc = t % a.nco; t /= a.nco;
   const int tx = t % a.ntx; t /= a.ntx;
   const int ty = t % a.nty; t /= a.nty;
-  const int tz = t % a.ntz; t /= a.ntz;
-  const int tc = t % a.nco;
-  const int b = t / a.nco;
+  const int tz = t % a.ntz;
+  const int b = t / a.ntz;
   const int x0 = tx * kTW, y0 = ty * kTH, z0 = tz * kTD, co0 = tc * kCOUT;
   const int zl = wave / kTH, yl = wave % kTH;   // this wave's input row
 

@@ -199,9 +199,14 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
           asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t0) : "v"(d[ra][0]), "v"(d[rb2][0]));
           asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t1) : "v"(d[ra][1]), "v"(d[rb2][1]));
         }
-        asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(vp[slot][r][0]) : "v"(t0), "v"(t1));
-        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]"
-            : "=v"(vp[slot][r][1]) : "v"(t1), "v"(t0));
+        // The two results of a row are MFMA A operands.  gfx950 does not interlock a VALU write with an MFMA that reads
+        // the register as SrcA/B within the next two issue slots (probed: v_pk_add_f32 / v_add_f32 -> v_mfma back to back
+        // or one instruction apart reads the OLD value), and the compiler cannot see through inline asm to add the wait
+        // states itself: the s_nop makes the pair safe wherever the scheduler puts the consuming MFMA.
+        asm("v_pk_add_f32 %0, %2, %3 op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+            "v_pk_add_f32 %1, %3, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]\n\t"
+            "s_nop 1"
+            : "=&v"(vp[slot][r][0]), "=&v"(vp[slot][r][1]) : "v"(t0), "v"(t1));
       }
     };
     load_patch(0);

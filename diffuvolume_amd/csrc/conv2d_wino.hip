@@ -46,6 +46,7 @@ struct Wino2dArgs {
   int B, Cin, H, W, Cout;
   int ntx, nty, nco;
   int act, fast_ok;
+  int dil;                // dilation: the block works on one of the dil*dil sub-sampled images (a dilation-1 problem)
 };
 
 // DEEP: the low-occupancy variant for launches that do not fill the chip (IGEV's 1/8 and 1/16 scales at batch 1):
@@ -64,12 +65,21 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;
 
+  // A 3x3 convolution with dilation d is d*d independent dilation-1 convolutions on the images sub-sampled at
+  // (ry + d*Y, rx + d*X): a block owns a 16x16 tile of ONE sub-image, and everything between the raw loads and the
+  // stores is the dilation-1 kernel.  The sub-image index is the fastest tile index, so the d*d blocks that share
+  // the same cache lines of input and output run side by side on one XCD.
   unsigned t = dv_xcd_remap(blockIdx.x, gridDim.x);
+  const int dil = a.dil;
+  const int sg = t % (unsigned)(dil * dil); t /= (unsigned)(dil * dil);
+  const int ry = sg / dil, rx = sg - ry * dil;
   const int tx = t % a.ntx; t /= a.ntx;
   const int ty = t % a.nty; t /= a.nty;
   const int tc = t % a.nco;
   const int b = t / a.nco;
-  const int x0 = tx * TW, y0 = ty * TH, co0 = tc * 32;
+  const int x0 = tx * TW, y0 = ty * TH, co0 = tc * 32;          // in sub-image coordinates
+  const int Hs = (a.H - ry + dil - 1) / dil, Ws = (a.W - rx + dil - 1) / dil;   // size of this sub-image
+  if (y0 >= Hs || x0 >= Ws) return;                              // (the tile grid is that of the largest sub-image)
 
   f32x4 acc[16][NT];
 #pragma unroll
@@ -88,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
   for (int i = 0; i < NS; ++i) {
     const int r = tid + 256 * i;
     const int yy = r / IX, xx = r - yy * IX;
-    const int y = y0 - 1 + yy, x = x0 - 1 + xx;
+    const int y = ry + dil * (y0 - 1 + yy), x = rx + dil * (x0 - 1 + xx);
     const bool ok = r < PRAW && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
     sob[i] = ok ? (unsigned)(y * a.W + x) * 4u : 0x80000000u;
     lro[i] = r < PRAW ? yy * RX + xx : IX;                   // lanes past the brick write a column no patch reads
@@ -249,8 +259,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
 
   // ---- epilogue: Y = At M A per tile; a lane (cout j, tiles 4kq..4kq+3) holds 4 consecutive x of four rows ----
   const int yb = y0 + 4 * wave, xb = x0 + 4 * kq;
-  if (yb >= a.H) return;
-  const bool fast = a.fast_ok && x0 + TW <= a.W && yb + 4 <= a.H;
+  if (yb >= Hs) return;
+  const bool fast = a.fast_ok && dil == 1 && x0 + TW <= a.W && yb + 4 <= a.H;
   const float slope = a.act == DV_ACT_RELU ? 0.f : (a.act == DV_ACT_LEAKY ? 0.01f : 1.f);
   const bool gen = a.act == DV_ACT_MISH || a.act == DV_ACT_SIGMOID || a.act == DV_ACT_TANH;
 #pragma unroll
@@ -259,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
     if (co >= a.Cout) continue;
     const float sc = a.ch_scale ? a.ch_scale[co] : 1.f;
     const float bi = a.ch_bias ? a.ch_bias[co] : 0.f;
-    const size_t cbase = (((size_t)b * a.Cout + co) * a.H + yb) * a.W + xb;
+    const size_t cbase = (((size_t)b * a.Cout + co) * a.H + (ry + dil * yb)) * a.W + (rx + dil * xb);
 #pragma unroll
     for (int tr = 0; tr < 2; ++tr) {
       float yv[2][4];
@@ -281,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int yr = 2 * tr + r;
-        const size_t o = cbase + (size_t)yr * a.W;
+        const size_t o = cbase + (size_t)(dil * yr) * a.W;
         if (fast) {
           f32x4 v;
 #pragma unroll
@@ -296,16 +306,17 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
             v = h + z * (v - h);
           }
           *reinterpret_cast<f32x4*>(a.out + o) = v;
-        } else if (yb + yr < a.H) {
+        } else if (yb + yr < Hs) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (xb + e < a.W) {
+            if (xb + e < Ws) {
+              const size_t oe = o + (size_t)(dil * e);
               float u = fmaf(yv[r][e], sc, bi);
-              if (a.residual) u += a.residual[o + e];
+              if (a.residual) u += a.residual[oe];
               u = dv_act(u, a.act);
-              if (a.mul) u *= a.mul[o + e];
-              if (a.blend_z) u = a.blend_h[o + e] + a.blend_z[o + e] * (u - a.blend_h[o + e]);
-              a.out[o + e] = u;
+              if (a.mul) u *= a.mul[oe];
+              if (a.blend_z) u = a.blend_h[oe] + a.blend_z[oe] * (u - a.blend_h[oe]);
+              a.out[oe] = u;
             }
         }
       }
@@ -368,12 +379,13 @@ extern "C" int dv_conv2d_wino_pack_weights_f32(const float* w, float* wpacked, i
   return dv_launch_status();
 }
 
-extern "C" int dv_conv2d_wino_cat_f32(const float* const* inputs, const int* channels, int n_inputs,
-                                      const float* wpacked, const float* ch_scale, const float* ch_bias,
-                                      const float* residual, const float* mul, const float* blend_z,
-                                      const float* blend_h, float* out, int B, int H, int W, int Cout, int act,
-                                      dv_stream_t stream) {
+extern "C" int dv_conv2d_wino_dil_cat_f32(const float* const* inputs, const int* channels, int n_inputs,
+                                          const float* wpacked, const float* ch_scale, const float* ch_bias,
+                                          const float* residual, const float* mul, const float* blend_z,
+                                          const float* blend_h, float* out, int B, int H, int W, int Cout,
+                                          int dilation, int act, dv_stream_t stream) {
   DV_REQUIRE_PTR(inputs);
+  DV_REQUIRE(dilation >= 1 && dilation <= 16, DV_ERR_UNSUPPORTED);
   DV_REQUIRE_PTR(channels);
   DV_REQUIRE_PTR(wpacked);
   DV_REQUIRE_PTR(out);
@@ -401,8 +413,9 @@ extern "C" int dv_conv2d_wino_cat_f32(const float* const* inputs, const int* cha
   a.B = B; a.Cin = cin; a.H = H; a.W = W; a.Cout = Cout; a.act = act;
   a.fast_ok = (W % 4 == 0) && dv_aligned16(out) && (!residual || dv_aligned16(residual)) &&
               (!mul || dv_aligned16(mul)) && (!blend_z || (dv_aligned16(blend_z) && dv_aligned16(blend_h)));
-  a.ntx = cdiv2(W, w2::TW); a.nty = cdiv2(H, w2::TH); a.nco = cdiv2(Cout, 32);
-  const long long blocks = (long long)B * a.nco * a.nty * a.ntx;
+  a.dil = dilation;
+  a.ntx = cdiv2(cdiv2(W, dilation), w2::TW); a.nty = cdiv2(cdiv2(H, dilation), w2::TH); a.nco = cdiv2(Cout, 32);
+  const long long blocks = (long long)B * a.nco * a.nty * a.ntx * dilation * dilation;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return DV_ERR_SHAPE;
   // launches that leave most of the chip empty run the deep-prefetch variant
   if (blocks < 512)
@@ -410,4 +423,13 @@ extern "C" int dv_conv2d_wino_cat_f32(const float* const* inputs, const int* cha
   else
     hipLaunchKernelGGL(conv2d_wino_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   return dv_launch_status();
+}
+
+extern "C" int dv_conv2d_wino_cat_f32(const float* const* inputs, const int* channels, int n_inputs,
+                                      const float* wpacked, const float* ch_scale, const float* ch_bias,
+                                      const float* residual, const float* mul, const float* blend_z,
+                                      const float* blend_h, float* out, int B, int H, int W, int Cout, int act,
+                                      dv_stream_t stream) {
+  return dv_conv2d_wino_dil_cat_f32(inputs, channels, n_inputs, wpacked, ch_scale, ch_bias, residual, mul, blend_z,
+                                    blend_h, out, B, H, W, Cout, 1, act, stream);
 }

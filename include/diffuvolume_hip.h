@@ -190,6 +190,13 @@ int dv_conv2d_wino_cat_f32(const float* const* inputs, const int* channels, int 
                            const float* ch_scale, const float* ch_bias, const float* residual, const float* mul,
                            const float* blend_z, const float* blend_h, float* out, int B, int H, int W, int Cout,
                            int act, dv_stream_t stream);
+/* The same with dilation 1..16 (the refinement network's dilated layers, KITTI12/models/submodule.py:251-306, and the
+ * dilated blocks of the 2-D feature CNNs): a dilation-d 3x3 convolution is d*d independent dilation-1 convolutions on the
+ * sub-sampled images, so each block runs the Winograd kernel on a 16x16 tile of one sub-image.  Same packed weights. */
+int dv_conv2d_wino_dil_cat_f32(const float* const* inputs, const int* channels, int n_inputs, const float* wpacked,
+                               const float* ch_scale, const float* ch_bias, const float* residual, const float* mul,
+                               const float* blend_z, const float* blend_h, float* out, int B, int H, int W, int Cout,
+                               int dilation, int act, dv_stream_t stream);
 
 /* Input assembly of that refinement (KITTI12/models/pwcnet_ddim.py:486-502), fused:
  *   frw = warp(right, disp)  (models/submodule.py:137-176, incl. its align_corners mismatch and >= 0.999 mask),

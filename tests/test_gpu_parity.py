@@ -884,6 +884,37 @@ def test_conv2d_winograd(cfg, monkeypatch):
     torch.testing.assert_close(out, direct, atol=2e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("cfg", [((8,), 32, 2, 16, 16, S.ACT_NONE), ((5, 7), 20, 3, 19, 41, S.ACT_TANH),
+                                 ((16, 8), 48, 4, 37, 70, S.ACT_RELU), ((12,), 33, 8, 40, 52, S.ACT_SIGMOID),
+                                 ((6,), 16, 16, 40, 130, S.ACT_NONE), ((4,), 8, 5, 7, 9, S.ACT_MISH)])
+def test_conv2d_winograd_dilated(cfg, monkeypatch):
+    """Dilated 3x3 layers on the Winograd kernel: a dilation-d convolution is d*d dilation-1 problems on the sub-sampled
+    images (ry + d*Y, rx + d*X).  Shapes where the sub-images differ in size (H, W not multiples of d), are smaller than
+    a tile, or the dilation exceeds the image; every epilogue option; against torch's fp64 convolution and the direct kernel."""
+    cins, cout, dil, h, w_, act = cfg
+    monkeypatch.setattr(S.Conv2dPlan, "WINO_MIN_BLOCKS", 0)
+    monkeypatch.setattr(S.Conv2dPlan, "WINO_MAX_DILATION", 16)       # the kernel supports 1..16; the plan uses it up to 4
+    g = _gen(43, str(cfg))
+    b = 2
+    xs = [torch.randn(b, c, h, w_, generator=g) for c in cins]
+    cin = sum(cins)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    res, m = torch.randn(b, cout, h, w_, generator=g), torch.randn(b, cout, h, w_, generator=g)
+    z, hh = torch.rand(b, cout, h, w_, generator=g), torch.randn(b, cout, h, w_, generator=g)
+    y = torch.nn.functional.conv2d(torch.cat(xs, 1).double(), w.double(), bias.double(), 1, dil, dil) + res.double()
+    y = {S.ACT_NONE: lambda t: t, S.ACT_RELU: torch.relu, S.ACT_TANH: torch.tanh, S.ACT_SIGMOID: torch.sigmoid,
+         S.ACT_MISH: lambda t: t * torch.tanh(torch.nn.functional.softplus(t))}[act](y)
+    ref = hh.double() + z.double() * (y * m.double() - hh.double())
+    plan = S.Conv2dPlan(dev(w), None, dilation=dil, act=act, bias=dev(bias))
+    assert plan.wino_packed is not None
+    out = plan([dev(t) for t in xs], residual=dev(res), mul=dev(m), blend=(dev(z), dev(hh)))
+    torch.testing.assert_close(out.cpu().double(), ref, atol=2e-5, rtol=1e-5)
+    plan.wino_packed = None                       # the same plan on the direct kernel
+    direct = plan([dev(t) for t in xs], residual=dev(res), mul=dev(m), blend=(dev(z), dev(hh)))
+    torch.testing.assert_close(out, direct, atol=2e-5, rtol=1e-5)
+
+
 def test_conv2d_winograd_c_abi():
     from diffuvolume_amd import _lib
     import ctypes
@@ -911,8 +942,8 @@ def test_conv2d_winograd_c_abi():
 
 def test_precision_switch_selects_kernels(monkeypatch):
     """'f32' (default) puts the 3x3x3 stride-1 layers and the 3x3 dilation-1 2-D layers on the Winograd kernels,
-    'f32_direct' keeps every layer on the direct implicit GEMMs; strided / dilated / 1x1 / single-channel layers are
-    direct either way."""
+    'f32_direct' keeps every layer on the direct implicit GEMMs; strided / 1x1 / single-channel layers are direct either
+    way (dilated 3x3 2-D layers run the Winograd kernel on their sub-sampled images)."""
     w3, w2 = torch.randn(32, 16, 3, 3, 3, device=DEV), torch.randn(32, 16, 3, 3, device=DEV)
     S.set_default_conv_precision(None)
     monkeypatch.delenv("DV_CONV_PRECISION", raising=False)
@@ -920,7 +951,7 @@ def test_precision_switch_selects_kernels(monkeypatch):
     assert not S.Conv3dPlan(w3, stride=2).wino
     assert not S.Conv3dPlan(torch.randn(1, 16, 3, 3, 3, device=DEV)).wino
     assert not S.Conv3dPlan(torch.randn(32, 16, 1, 1, 1, device=DEV)).wino
-    assert S.Conv2dPlan(w2, dilation=2).wino_packed is None and S.Conv2dPlan(w2, stride=2).wino_packed is None
+    assert S.Conv2dPlan(w2, dilation=2).wino_packed is not None and S.Conv2dPlan(w2, stride=2).wino_packed is None
     try:
         S.set_default_conv_precision("f32_direct")
         assert not S.Conv3dPlan(w3).wino and S.Conv2dPlan(w2).wino_packed is None

@@ -73,10 +73,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
   const int dil = a.dil;
   const int sg = t % (unsigned)(dil * dil); t /= (unsigned)(dil * dil);
   const int ry = sg / dil, rx = sg - ry * dil;
+  const int tc = t % a.nco; t /= a.nco;       // the output-channel slices of a tile side by side too: one HBM read of the brick
   const int tx = t % a.ntx; t /= a.ntx;
-  const int ty = t % a.nty; t /= a.nty;
-  const int tc = t % a.nco;
-  const int b = t / a.nco;
+  const int ty = t % a.nty;
+  const int b = t / a.nty;
   const int x0 = tx * TW, y0 = ty * TH, co0 = tc * 32;          // in sub-image coordinates
   const int Hs = (a.H - ry + dil - 1) / dil, Ws = (a.W - rx + dil - 1) / dil;   // size of this sub-image
   if (y0 >= Hs || x0 >= Ws) return;                              // (the tile grid is that of the largest sub-image)

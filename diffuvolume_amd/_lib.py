@@ -78,6 +78,9 @@ SIGNATURES = {
     "dv_ddim_step": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, POINTER(DvDdimCoef), P]),
     "dv_context_upsample_f32": (c_int, [P, P, P, I, I, I, c_float, I, P]),
     "dv_allpairs_corr_f32": (c_int, [P, P, P, P, I, I, I, I, I, P]),
+    "dv_conv2d_1in_f32": (c_int, [P, P, P, P, I, I, I, I, I, I, P]),
+    "dv_resize_bilinear_ac_f32": (c_int, [P, P, I, I, I, I, I, P]),
+    "dv_avg_pool3s2_f32": (c_int, [P, P, I, I, I, P]),
     "dv_geo_filter_lookup_f32": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "dv_masked_metrics_f32": (c_int, [P, P, P, P, I, I, P]),
 }

@@ -4,8 +4,9 @@ convention, so ``IGEVDiffusionLoop`` (or the reference's own ``ddim_sample``) ca
 
 On HIP (csrc/conv2d.hip): every 3x3 / 1x1 convolution with its bias and ReLU / sigmoid / tanh, and the ConvGRU gate
 arithmetic in the epilogues -- ``convr`` emits ``r*h`` directly, ``convq`` emits ``(1-z)*h + z*tanh(.)`` -- so a
-ConvGRU is three launches; the convolutions read ``[h | x...]`` as a virtual concatenation (``dv_conv2d_cat_f32``).  PyTorch: the 7x7 single-channel ``convd1`` (0.2 GFLOP),
-the motion encoder's two small ``torch.cat``, average pooling and bilinear interpolation between the three scales.
+ConvGRU is three launches; the convolutions read ``[h | x...]`` as a virtual concatenation (``dv_conv2d_cat_f32``).  The 7x7 single-channel ``convd1``, the 3x3 average
+pooling and the bilinear interpolation between the three scales have their own small kernels (csrc/update_glue.hip); PyTorch
+keeps one ``torch.cat`` (the disparity channel appended to the motion features).
 """
 from __future__ import annotations
 
@@ -13,6 +14,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import _lib
 from .submodule import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, Conv2dPlan
 
 
@@ -106,13 +108,41 @@ class BasicMotionEncoder(_Planned):
     def forward(self, disp, corr):
         p = self.plans()
         cor = p["convc2"](p["convc1"](corr))
-        disp_ = p["convd2"](F.relu(self.convd1(disp)))
-        out = p["conv"](torch.cat([cor, disp_], dim=1))
+        disp_ = p["convd2"](self._convd1(disp))
+        out = p["conv"]([cor, disp_])                   # virtual concatenation: torch.cat([cor, disp_]) is never materialised
         return torch.cat([out, disp], dim=1)
+
+    def _convd1(self, disp):
+        """relu(convd1(disp)): the 7x7 single-input-channel convolution on its own VALU kernel (MIOpen picks a naive
+        solver for this shape: 0.7 ms per call at batch 4)."""
+        if not _hip_ok(disp):
+            return F.relu(self.convd1(disp))
+        disp = disp.contiguous()
+        b, _, h, w = disp.shape
+        out = torch.empty((b, self.convd1.out_channels, h, w), dtype=torch.float32, device=disp.device)
+        wt, bias = self.convd1.weight.contiguous(), self.convd1.bias
+        with torch.cuda.device(disp.device):
+            _lib.check(_lib.load().dv_conv2d_1in_f32(disp.data_ptr(), wt.data_ptr(), _lib.ptr(bias), out.data_ptr(), b, h, w,
+                                                     out.shape[1], int(wt.shape[-1]), ACT_RELU, _lib.stream_ptr()),
+                       "dv_conv2d_1in_f32")
+        return out
+
+
+def _hip_ok(x):
+    return x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and x.requires_grad)
 
 
 def pool2x(x):
-    return F.avg_pool2d(x, 3, stride=2, padding=1)
+    """update.py:96-97.  HIP (`dv_avg_pool3s2_f32`) for CUDA fp32 inference tensors."""
+    if not _hip_ok(x):
+        return F.avg_pool2d(x, 3, stride=2, padding=1)
+    x = x.contiguous()
+    b, c, h, w = x.shape
+    out = torch.empty((b, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().dv_avg_pool3s2_f32(x.data_ptr(), out.data_ptr(), b * c, h, w, _lib.stream_ptr()),
+                   "dv_avg_pool3s2_f32")
+    return out
 
 
 def pool4x(x):
@@ -120,7 +150,17 @@ def pool4x(x):
 
 
 def interp(x, dest):
-    return F.interpolate(x, dest.shape[2:], mode="bilinear", align_corners=True)
+    """update.py:100-102.  HIP (`dv_resize_bilinear_ac_f32`) for CUDA fp32 inference tensors."""
+    if not _hip_ok(x):
+        return F.interpolate(x, dest.shape[2:], mode="bilinear", align_corners=True)
+    x = x.contiguous()
+    b, c, h, w = x.shape
+    H, W = int(dest.shape[2]), int(dest.shape[3])
+    out = torch.empty((b, c, H, W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().dv_resize_bilinear_ac_f32(x.data_ptr(), out.data_ptr(), b * c, h, w, H, W,
+                                                         _lib.stream_ptr()), "dv_resize_bilinear_ac_f32")
+    return out
 
 
 class BasicMultiUpdateBlock(_Planned):

@@ -310,6 +310,18 @@ int dv_ddim_step(const float* disp, const float* unc, const float* used, const f
 int dv_context_upsample_f32(const float* disp_low, const float* weights, float* out, int B, int h, int w,
                             float scale, int apply_softmax, dv_stream_t stream);
 
+/* ---- IGEV: the small per-iteration operators around the ConvGRUs (KITTI15/core/update.py) ----
+ * dv_conv2d_1in_f32: nn.Conv2d(1, Cout, k, padding=k/2) + bias + activation on a single-channel image (the motion
+ *   encoder's 7x7 `convd1` on the disparity, update.py:86,:92).  in [B,1,H,W]; w [Cout,1,k,k] (k = 3, 5, 7); out [B,Cout,H,W].
+ * dv_resize_bilinear_ac_f32: F.interpolate(x, (H,W), mode='bilinear', align_corners=True) (`interp`, update.py:100-102),
+ *   PyTorch's source-index arithmetic.  in [BC,h,w] -> out [BC,H,W].
+ * dv_avg_pool3s2_f32: F.avg_pool2d(x, 3, stride=2, padding=1) with the padded zeros counted (`pool2x`, update.py:96-97).
+ *   in [BC,H,W] -> out [BC,(H-1)/2+1,(W-1)/2+1]. */
+int dv_conv2d_1in_f32(const float* in, const float* w, const float* bias, float* out, int B, int H, int W, int Cout,
+                      int k, int act, dv_stream_t stream);
+int dv_resize_bilinear_ac_f32(const float* in, float* out, int BC, int h, int w, int H, int W, dv_stream_t stream);
+int dv_avg_pool3s2_f32(const float* in, float* out, int BC, int H, int W, dv_stream_t stream);
+
 /* ---- IGEV: all-pairs correlation along the epipolar line + its level-1 pooling --------
  * Combined_Geo_Encoding_Volume.corr (KITTI15/core/geometry_ddim.py:72-80: einsum 'aijk,aijh->ajkh') and the
  * avg_pool2d([1,2]) of the pyramid (:28-30), once per stereo pair:

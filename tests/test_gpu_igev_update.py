@@ -2,6 +2,7 @@
 convolution with the gate arithmetic fused, vs the reference's golden vectors and the oracle."""
 import pytest
 import torch
+import torch.nn.functional as F
 
 from conftest import load_golden
 from diffuvolume_amd import submodule as S
@@ -118,6 +119,30 @@ def test_ddim_loop_with_the_real_update_block():
                              None, noise=NoiseTape(135))
     d = (final.cpu() - final_ref).abs()
     assert float(d.median()) < 2e-3 and float(d.mean()) < 5e-2, (float(d.median()), float(d.mean()))
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 24, 78), (1, 3, 7, 9), (1, 2, 1, 5), (2, 4, 12, 39)])
+def test_update_glue_kernels_vs_torch(shape):
+    """csrc/update_glue.hip: `pool2x`, `interp` (bilinear, align_corners=True) and the single-input-channel 7x7 `convd1`
+    of the motion encoder (KITTI15/core/update.py:86-102) against PyTorch's own operators on the CPU."""
+    from diffuvolume_amd import update as U
+    b, c, h, w = shape
+    g = _gen(151, str(shape))
+    x = torch.randn(b, c, h, w, generator=g)
+    torch.testing.assert_close(U.pool2x(dev(x)).cpu(), F.avg_pool2d(x, 3, stride=2, padding=1), atol=1e-6, rtol=1e-6)
+    for size in ((2 * h, 2 * w), (2 * h - 1, 2 * w + 1), (h, w), (1, 1)):
+        dest = torch.empty(b, c, *size)
+        ref = F.interpolate(x, size, mode="bilinear", align_corners=True)
+        torch.testing.assert_close(U.interp(dev(x), dev(dest)).cpu(), ref, atol=1e-6, rtol=1e-6)
+    enc = U.BasicMotionEncoder(ARGS)
+    with torch.no_grad():
+        enc.convd1.weight.copy_(torch.randn(enc.convd1.weight.shape, generator=g) * 0.1)
+        enc.convd1.bias.copy_(torch.randn(enc.convd1.bias.shape, generator=g) * 0.1)
+        d = torch.rand(b, 1, h, w, generator=g) * 40
+        ref = F.relu(enc.convd1.double()(d.double())).float()
+        enc = enc.float().to(DEV)
+        out = enc._convd1(dev(d))
+    assert float((out.cpu() - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
 
 
 def test_conv2d_over_virtual_concatenation():

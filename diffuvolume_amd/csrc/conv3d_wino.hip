@@ -173,8 +173,19 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
       const int piece = wave + 4 * q;
+#ifdef DV_WINO_BUILTIN_DMA
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 256),
                                        (__attribute__((address_space(3))) void*)(ub + piece * 256), 16, 0, 0);
+#else
+      // Issued as inline asm rather than through the builtin: the compiler treats an LDS-DMA as an LDS store that any
+      // later LDS store may alias and answers the next `ds_write` of the raw brick with s_waitcnt vmcnt(0) -- i.e. the
+      // first commit group of every chunk waited for the DMA issued 16 MFMAs earlier.  Its completion is covered by
+      // the manual s_waitcnt vmcnt + barrier at the top of the next chunk; not counting it makes the compiler's own
+      // vmcnt waits for the raw registers stricter, never looser (vector memory operations complete in order).
+      const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(ub + piece * 256);
+      const float* gp = src + piece * 256;
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(gp) : "m0", "memory");
+#endif
     }
   };
 

@@ -184,7 +184,9 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
       // vmcnt waits for the raw registers stricter, never looser (vector memory operations complete in order).
       const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(ub + piece * 256);
       const float* gp = src + piece * 256;
-      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(gp) : "m0", "memory");
+      unsigned m0_saved;       // M0 is reserved by the compiler: hand it back as found
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(m0_saved) : "s"(lds_addr), "v"(gp) : "memory");
 #endif
     }
   };
@@ -294,6 +296,9 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
       if (p4 == 0 && kd < 2) load_patch(kd + 1);
       if (g == 0 && nxt) dma_u(c0 + KC, u_s + (cur ^ 1) * U_CHUNK);
       if (g >= 2 && g < 2 + KC && nxt) commit_next_cl(g - 2);
+      // (all KC*NS refill loads in ONE group would let the compiler count them exactly -- its waits before the commits
+      // become vmcnt(11), (10), ... instead of (2), (1), (0) per group -- but bunching the loads costs more than the
+      // coarser waits: 46.8 vs 47.4 pairs/s)
       if (g >= 2 + KC && g < 2 + 2 * KC && refill) fetch_raw_cl(c0 + 2 * KC, g - 2 - KC);
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt)

@@ -73,12 +73,20 @@ __global__ __launch_bounds__(256) void upsample_softmax_regress_kernel(const flo
     lin_src<ALIGN>((k), D, K, i0_, i1_, l0_, l1_);     \
     (out) = l0_ * c[i0_] + l1_ * c[i1_];               \
   }
+  // Softmax shift = max_k v_k.  Between two neighbouring slices the four bins are a linear ramp, so the maximum sits on
+  // the outer bins of a segment (align_corners=False: k = 4d + 1 and 4d + 2; k = 0 and 4D - 1 are the clamped ends):
+  // half the bins are enough.
+  // (In floating point an inner bin can exceed that by an ulp when the two slices are nearly equal: its exponential is
+  // then 1 + O(ulp), harmless.  The maximum of the 48 SLICES is not a valid shift: bins never reach a slice value, and
+  // with steep costs every exponential would underflow.)
   float m = -INFINITY;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    float v;
-    DV_VK(k, v);
-    m = fmaxf(m, v);
+    if (ALIGN || (k & 3) == 1 || (k & 3) == 2 || k == 0 || k == K - 1) {     // (align_corners=True: bins are not periodic)
+      float v;
+      DV_VK(k, v);
+      m = fmaxf(m, v);
+    }
   }
   // exp(v_k - m) is evaluated once and kept (4D values per pixel: the kernel runs one wave per SIMD on the
   // whole 512-entry register file); the later passes only divide and accumulate, in the reference's order

@@ -102,25 +102,23 @@ __global__ __launch_bounds__(256) void upsample_softmax_regress_kernel(const flo
   }
   // p_k = e_k * (1/s): one correctly rounded division per pixel instead of 4D (each is ~10 instructions);
   // differs from e_k / s by at most one ulp of p_k
+  // The normalisation is applied to the two sums, not to the 4D exponentials (sum_k (e_k / s) k = (sum_k e_k k) / s up
+  // to rounding): one reciprocal and two multiplications per pixel instead of 4D.
   const float rs = 1.f / s;
   float dsp = 0.f;
   if (disp_in) {           // uncertainty about an externally refined disparity (pwcnet_ddim.py:548-552)
     dsp = disp_in[i];
-#pragma unroll
-    for (int k = 0; k < K; ++k) e[k] = e[k] * rs;
   } else {
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      e[k] = e[k] * rs;
-      dsp += e[k] * (float)k;
-    }
+    for (int k = 0; k < K; ++k) dsp += e[k] * (float)k;
+    dsp *= rs;
     disp[i] = dsp;
   }
   if (unc) {
     float u = 0.f;
 #pragma unroll
     for (int k = 0; k < K; ++k) u += fabsf(dsp - (float)k) * e[k];
-    unc[i] = u;
+    unc[i] = u * rs;
   }
 #undef DV_VK
 }

@@ -92,13 +92,14 @@ __global__ __launch_bounds__(256) void upsample_softmax_regress_kernel(const flo
   // whole 512-entry register file); the later passes only divide and accumulate, in the reference's order
   // (softmax first, then the expectation / the absolute moment).
   float e[K];
-  float s = 0.f;
+  float s = 0.f, num = 0.f;               // sum_k e_k and sum_k e_k k in the same pass
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     float v;
     DV_VK(k, v);
     e[k] = dv_exp_le0(v - m);
     s += e[k];
+    num += e[k] * (float)k;
   }
   // p_k = e_k * (1/s): one correctly rounded division per pixel instead of 4D (each is ~10 instructions);
   // differs from e_k / s by at most one ulp of p_k
@@ -109,9 +110,7 @@ __global__ __launch_bounds__(256) void upsample_softmax_regress_kernel(const flo
   if (disp_in) {           // uncertainty about an externally refined disparity (pwcnet_ddim.py:548-552)
     dsp = disp_in[i];
   } else {
-#pragma unroll
-    for (int k = 0; k < K; ++k) dsp += e[k] * (float)k;
-    dsp *= rs;
+    dsp = num * rs;
     disp[i] = dsp;
   }
   if (unc) {

@@ -18,8 +18,12 @@ CSRC = PKG / "csrc"
 OBJ = CSRC / "build"
 LIB = PKG / "libdiffuvolume_hip.so"
 ARCH = "gfx950"
+# -fno-slp-vectorize: under plain -O3 the compiler packs adjacent scalar fp32 adds / multiplies into v_pk_* instructions
+# (plus the v_pk_mov that build the operand pairs); on gfx950 that is slower than the scalar form -- measured on the
+# bench: single-channel head 2.90 -> 2.48 ms per step, Winograd epilogues -0.5 %, nothing slower (48.2 -> 48.5 pairs/s).
+# The packed instructions this library wants (the Winograd input transform) are written out by hand.
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-         "-fno-gpu-rdc", "-ffp-contract=on"]
+         "-fno-gpu-rdc", "-ffp-contract=on", "-fno-slp-vectorize"]
 
 
 def _hipcc() -> str:

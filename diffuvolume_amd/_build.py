@@ -33,6 +33,18 @@ def _hipcc() -> str:
     return exe
 
 
+def csrc_sha16() -> str:
+    """Fingerprint of the kernel sources (csrc/*.hip, csrc/*.h, include/*.h): stamped into the profiles collected by
+    tools/ and compared by bench.py, so that counter figures of an older kernel are never quoted for the current one
+    (the GPU box has no .git, so the commit id is not available there)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) + list((PKG.parent / "include").glob("*.h"))):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def _stale(target: Path, deps) -> bool:
     if not target.exists():
         return True

@@ -185,7 +185,9 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
       const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(ub + piece * 256);
       const float* gp = src + piece * 256;
       unsigned m0_saved;       // M0 is reserved by the compiler: hand it back as found
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+      // (s_nop 0: gfx9 needs one wait state between a scalar write of M0 and the LDS-DMA that reads it; the hazard
+      // recogniser does not look inside inline asm -- tests/test_isa_lint.py checks the compiled stream)
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
                    : "=&s"(m0_saved) : "s"(lds_addr), "v"(gp) : "memory");
 #endif
     }

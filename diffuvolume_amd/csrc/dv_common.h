@@ -50,7 +50,8 @@ __device__ __forceinline__ float dv_act(float v, int act) {
 // overflow / denormal handling that cannot occur here: results below 2^-126 flush to zero next to a sum >= 1).
 __device__ __forceinline__ float dv_exp_le0(float x) {
   const float L = 1.44269504088896340736f, LL = 1.92596299112661746e-8f;
-  x = fmaxf(x, -104.f);             // exp(-104) is below the smallest denormal: also keeps -inf from becoming inf - inf
+  x = x < -104.f ? -104.f : x;      // exp(-104) is below the smallest denormal: also keeps -inf from becoming inf - inf;
+                                    // a NaN argument stays NaN (fmaxf would turn it into a ~0 term and hide it)
   const float t = x * L;
   const float r = fmaf(x, L, -t) + x * LL;
   const float p = __builtin_amdgcn_exp2f(t);

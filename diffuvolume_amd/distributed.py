@@ -12,13 +12,14 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
+def init_from_env(backend: str | None = None, force: bool = False) -> Tuple[int, int, int]:
     """(rank, world_size, local_rank) from torchrun's environment; initialises the default
-    process group when WORLD_SIZE > 1 (backend 'nccl' == RCCL on ROCm, 'gloo' on CPU)."""
+    process group when WORLD_SIZE > 1 (backend 'nccl' == RCCL on ROCm, 'gloo' on CPU), or -- ``force`` -- also for
+    a single rank (a one-rank RCCL group: the same code path as N ranks, on one GPU)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -52,7 +53,7 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
 
 def barrier_and_max(seconds: float, device) -> float:
     """Barrier, then the MAX over ranks of a local duration (bench.py contract)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())

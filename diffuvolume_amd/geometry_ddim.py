@@ -58,7 +58,7 @@ class Combined_Geo_Encoding_Volume:
             timed("allpairs_corr", 2.0 * B * H * W1 * W2 * C, 4.0 * (fmap1.numel() + fmap2.numel() + corr0.numel() + corr1.numel()),
                   lambda: _lib.check(lib.dv_allpairs_corr_f32(fmap1.data_ptr(), fmap2.data_ptr(), corr0.data_ptr(),
                                                               corr1.data_ptr(), B, C, H, W1, W2, _lib.stream_ptr()),
-                                     "dv_allpairs_corr_f32"))
+                                     "dv_allpairs_corr_f32"), issued=2.0 * B * H * W1 * W2 * C)
         return corr0, corr1
 
     @staticmethod

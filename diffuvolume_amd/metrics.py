@@ -88,7 +88,7 @@ class MetricAccumulator:
     def reduce(self, group=None) -> Dict[str, float]:
         import torch.distributed as dist
         state = self.state.clone()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.is_available() and dist.is_initialized():     # also a one-rank group: same RCCL path as N ranks
             if dist.get_backend(group) == "gloo":          # CPU rendezvous (tests on a 1-GPU box): reduce on the host
                 state = state.cpu()
             dist.all_reduce(state, op=dist.ReduceOp.SUM, group=group)

@@ -12,29 +12,35 @@ class KernelTimer:
     active: Optional["KernelTimer"] = None
 
     def __init__(self):
-        self.records = defaultdict(list)     # tag -> [(start, end, flops, bytes)]
+        self.records = defaultdict(list)     # tag -> [(start, end, flops, bytes, issued matrix-pipe flops)]
 
-    def launch(self, tag: str, flops: float, nbytes: float, fn: Callable[[], None]) -> None:
+    def launch(self, tag: str, flops: float, nbytes: float, fn: Callable[[], None], issued: float = 0.0) -> None:
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
         s.record()
         fn()
         e.record()
-        self.records[tag].append((s, e, flops, nbytes))
+        self.records[tag].append((s, e, flops, nbytes, issued))
 
     def summary(self) -> Dict[str, dict]:
         torch.cuda.synchronize()
         out = {}
         for tag, recs in self.records.items():
-            ms = sum(s.elapsed_time(e) for s, e, _, _ in recs)
+            ms = sum(r[0].elapsed_time(r[1]) for r in recs)
             out[tag] = {"launches": len(recs), "total_ms": ms, "avg_ms": ms / len(recs),
-                        "flops": sum(r[2] for r in recs), "bytes": sum(r[3] for r in recs)}
+                        "flops": sum(r[2] for r in recs), "bytes": sum(r[3] for r in recs),
+                        "issued_flops": sum(r[4] for r in recs)}
         return out
 
 
-def timed(tag: str, flops: float, nbytes: float, fn: Callable[[], None]) -> None:
+WINO_MULT_REDUCTION = 2.25     # F(2x2,3x3): 16 multiplies per 2x2 outputs and (depth tap, channel) instead of 36
+
+
+def timed(tag: str, flops: float, nbytes: float, fn: Callable[[], None], issued: float = 0.0) -> None:
+    """``flops`` = algorithmic (direct-convolution) count; ``issued`` = flops the kernel puts through the MATRIX pipe
+    (0 for vector-ALU kernels; algorithmic / 2.25 for the Winograd forms)."""
     t = KernelTimer.active
     if t is None:
         fn()
     else:
-        t.launch(tag, flops, nbytes, fn)
+        t.launch(tag, flops, nbytes, fn, issued)

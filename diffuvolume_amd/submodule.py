@@ -16,7 +16,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from .profiling import timed
+from .profiling import WINO_MULT_REDUCTION, timed
 
 __all__ = ["build_gwc_volume", "build_concat_volume", "build_concat_attention_volume",
            "disparity_regression", "upsample_softmax_regress", "Conv3dPlan", "Conv2dPlan", "Deconv3dPlan",
@@ -356,7 +356,7 @@ class Conv3dPlan:
                                                                 _lib.ptr(in_scale), _lib.ptr(residual),
                                                                 out.data_ptr(), b, cin, d, h, w, self.cout,
                                                                 self.act, _lib.stream_ptr()),
-                                         "dv_conv3d_wino_f32"))
+                                         "dv_conv3d_wino_f32"), issued=2.0 * out.numel() * cin * 27 / WINO_MULT_REDUCTION)
                 return out
             timed(f"conv3d_k{self.k}s{self.stride}_co{self.cout}" + ("" if in_scale is None else "_filter"),
                   2.0 * out.numel() * cin * self.k ** 3, nb,
@@ -364,7 +364,7 @@ class Conv3dPlan:
                                                        _lib.ptr(self.shift), _lib.ptr(in_scale),
                                                        _lib.ptr(residual), out.data_ptr(), b, cin, d, h, w,
                                                        self.cout, self.k, self.stride, self.act,
-                                                       _lib.stream_ptr()), "dv_conv3d_f32"))
+                                                       _lib.stream_ptr()), "dv_conv3d_f32"), issued=(2.0 * out.numel() * cin * self.k ** 3 if self.cout > 1 else 0.0))
         return out
 
 
@@ -442,7 +442,7 @@ class Conv2dPlan:
                       lambda: _lib.check(lib.dv_conv2d_s2_f32(x.data_ptr(), self.wpacked.data_ptr(), _lib.ptr(self.scale),
                                                               _lib.ptr(self.shift), _lib.ptr(residual), out.data_ptr(), b,
                                                               cin, h, w, self.cout, self.k, self.act, _lib.stream_ptr()),
-                                         "dv_conv2d_s2_f32"))
+                                         "dv_conv2d_s2_f32"), issued=2.0 * out.numel() * cin * self.k ** 2)
             return out
 
         def same(t, name):
@@ -471,7 +471,7 @@ class Conv2dPlan:
                                                                         _lib.ptr(residual), _lib.ptr(mul), _lib.ptr(bz),
                                                                         _lib.ptr(bh), out.data_ptr(), b, h, w, self.cout,
                                                                         d, self.act, _lib.stream_ptr()),
-                                         "dv_conv2d_wino_dil_cat_f32"))
+                                         "dv_conv2d_wino_dil_cat_f32"), issued=2.0 * out.numel() * cin * 9 / WINO_MULT_REDUCTION)
             return out
         # launches too small to fill the chip (a single IGEV pair at 1/8 and 1/16 resolution): K-split over the input
         # channels, partial tiles in a scratch buffer, fused epilogue in the reduction kernel
@@ -491,7 +491,7 @@ class Conv2dPlan:
                                                                       _lib.ptr(bh), out.data_ptr(), scratch.data_ptr(),
                                                                       kslices, b, h, w, self.cout, self.k, self.dilation,
                                                                       self.act, _lib.stream_ptr()),
-                                         "dv_conv2d_cat_ksplit_f32"))
+                                         "dv_conv2d_cat_ksplit_f32"), issued=2.0 * out.numel() * cin * self.k ** 2)
             return out
         if parts is not None:
             import ctypes
@@ -504,7 +504,7 @@ class Conv2dPlan:
                                                                _lib.ptr(self.scale), _lib.ptr(self.shift), _lib.ptr(residual),
                                                                _lib.ptr(mul), _lib.ptr(bz), _lib.ptr(bh), out.data_ptr(), b, h, w,
                                                                self.cout, self.k, self.dilation, self.act, _lib.stream_ptr()),
-                                         "dv_conv2d_cat_f32"))
+                                         "dv_conv2d_cat_f32"), issued=2.0 * out.numel() * cin * self.k ** 2)
             return out
         with torch.cuda.device(x.device):
             nb = 4.0 * (x.numel() + out.numel() * (1 + extra))
@@ -513,7 +513,7 @@ class Conv2dPlan:
                                                              _lib.ptr(self.shift), _lib.ptr(residual), _lib.ptr(mul),
                                                              _lib.ptr(bz), _lib.ptr(bh), out.data_ptr(), b, cin, h, w,
                                                              self.cout, self.k, self.dilation, self.act,
-                                                             _lib.stream_ptr()), "dv_conv2d_gated_f32"))
+                                                             _lib.stream_ptr()), "dv_conv2d_gated_f32"), issued=2.0 * out.numel() * cin * self.k ** 2)
         return out
 
 
@@ -586,7 +586,7 @@ class Deconv3dPlan:
                           lambda: _lib.check(lib.dv_deconv3d_k3s2_redir_f32(
                               x.data_ptr(), self.wpacked.data_ptr(), _lib.ptr(self.shift), skip.data_ptr(),
                               self.redir_w.data_ptr(), out.data_ptr(), b, cin, d, h, w, self.cout, self.cskip, self.act,
-                              _lib.stream_ptr()), "dv_deconv3d_k3s2_redir_f32"))
+                              _lib.stream_ptr()), "dv_deconv3d_k3s2_redir_f32"), issued=2.0 * x.numel() * self.cout * 27 + 2.0 * out.numel() * self.cskip)
                 return out
             residual = self.redir_plan(skip)
         if residual is not None:
@@ -598,7 +598,7 @@ class Deconv3dPlan:
             timed(f"deconv3d_k{self.k}s2", 2.0 * x.numel() * self.cout * self.k ** 3, nb,
                   lambda: _lib.check(self._run(x.data_ptr(), self.wpacked.data_ptr(), _lib.ptr(self.scale),
                                                _lib.ptr(self.shift), _lib.ptr(residual), out.data_ptr(), b, cin, d, h,
-                                               w, self.cout, self.act, _lib.stream_ptr()), self._name))
+                                               w, self.cout, self.act, _lib.stream_ptr()), self._name), issued=2.0 * x.numel() * self.cout * self.k ** 3)
         return out
 
 
@@ -689,5 +689,5 @@ def window_attention(x: torch.Tensor, qkv_w: torch.Tensor, qkv_b: torch.Tensor, 
               lambda: _lib.check(lib.dv_window_attn3d_f32(x.data_ptr(), qkv_w.data_ptr(), qkv_b.data_ptr(),
                                                           proj_w.data_ptr(), proj_b.data_ptr(), out.data_ptr(),
                                                           b, c, d, h, w, heads, _lib.stream_ptr()),
-                                 "dv_window_attn3d_f32"))
+                                 "dv_window_attn3d_f32"), issued=ntok * (2.0 * c * 3 * c + 2.0 * c * c + 4.0 * 64 * c))
     return out

@@ -53,13 +53,20 @@ def _keep(disp, unc, used, model):
 
 
 def _stats(d, unc=None):
-    """Distance statistics of one step.  ``frac_gt_1e-3`` is the raw contract figure.  ``frac_gt_bar`` applies the
-    same 1e-3 px bar on the pixels the reference itself calls confident (uncertainty = sum_k p_k |k - disp| < 3 px,
-    acv_ddim.py:325-330) and lets it grow with the spread elsewhere, 1e-3 * unc / 3: a soft-argmax moves by at most
-    unc * max|d cost| when the cost moves, so the disparity of a flat distribution (untrained weights: unc ~ 50 px)
-    is 17x more sensitive to the last bit of the fp32 cost than that of a trained, peaked one (unc ~ 1-3 px)."""
+    """Distance statistics of one step.
+    ``frac_gt_1e-3`` is the RAW contract figure over all pixels.
+    ``share_unc_lt_3`` is the share of pixels the reference itself calls confident (uncertainty = sum_k p_k |k - disp|
+    < 3 px, its own renewal criterion, acv_ddim.py:325-330) and ``frac_gt_1e-3_where_unc_lt_3`` the raw 1e-3 px bar on
+    exactly those pixels -- unscaled, so it can fail.
+    ``frac_gt_bar`` is a builder-defined diagnostic, NOT the contract: the bar grows as unc/3 on the other pixels (a
+    soft-argmax moves by at most unc * max|d cost| when the cost moves, so the disparity of a flat distribution --
+    untrained weights: unc ~ 50 px -- is 17x more sensitive to the last bit of the fp32 cost than a peaked one)."""
     s = {"mean_abs_px": float(d.mean()), "frac_gt_1e-3": float((d > BAR_PX).float().mean()), "max_px": float(d.max())}
     if unc is not None:
+        conf = unc < UNC_CONFIDENT
+        s["share_unc_lt_3"] = float(conf.float().mean())
+        s["frac_gt_1e-3_where_unc_lt_3"] = float((d[conf] > BAR_PX).float().mean()) if bool(conf.any()) else 0.0
+        s["max_px_where_unc_lt_3"] = float(d[conf].max()) if bool(conf.any()) else 0.0
         bar = BAR_PX * torch.clamp(unc / UNC_CONFIDENT, min=1.0)
         s["frac_gt_bar"] = float((d > bar).float().mean())
         s["unc_mean_px"] = float(unc.mean())

@@ -51,3 +51,34 @@ def test_too_few_devices_is_an_error():
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
     assert r.returncode != 0 and "refusing" in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]      # and no JSON line with a wrong n_gpus
+
+
+def test_self_launch_refused_under_a_profiler():
+    """rocprofv3's preloaded tool library initialises the GPU in the parent: starting workers from there is the
+    exec-after-init hop the pool forbids."""
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], env={"ROCPROF_OUTPUT_PATH": "/tmp/x",      # what rocprofv3 exports to its child
+                                                                   "DV_BENCH_OVERSUBSCRIBE": "1"})
+    assert r.returncode != 0 and "profiled parent" in r.stderr
+
+
+def test_device_count_without_the_runtime():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", ROOT / "bench.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    old = {k: os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")}
+    try:
+        for k in old:
+            os.environ.pop(k, None)
+        n = mod.visible_gpu_count()
+        assert n >= 0
+        os.environ["HIP_VISIBLE_DEVICES"] = ""
+        assert mod.visible_gpu_count() == 0
+        os.environ["HIP_VISIBLE_DEVICES"] = "0"
+        assert mod.visible_gpu_count() == min(n, 1)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

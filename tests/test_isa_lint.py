@@ -25,11 +25,16 @@ def regs(tok):
     return list(range(int(m.group(1)), int(m.group(2)) + 1))
 
 
-def lint(asm_text):
-    """-> (violations, number of inline-asm VALU producers seen, number of MFMAs seen)."""
+def lint(asm_text, m0_report=None):
+    """-> (violations, number of inline-asm VALU producers seen, number of MFMAs seen).  ``m0_report`` (a dict) receives
+    the second check: an LDS-DMA (``*_load_lds_*`` / ``buffer_load ... lds``) reads M0, and gfx9 needs one wait state
+    between a scalar write of M0 and that read; the compiler's hazard recogniser does not look inside inline asm, so
+    every DMA whose M0 write sits in an ASMSTART/ASMEND block must be at least one slot behind it."""
     in_asm, slot = False, 0
     written = {}            # vgpr -> slot index of the inline-asm instruction that wrote it last
     bad, n_prod, n_mfma = [], 0, 0
+    m0_written_asm = None   # slot of the last inline-asm write of m0 (None once the compiler wrote it: that one it guards)
+    m0_bad, n_dma = [], 0
     for raw in asm_text.splitlines():
         line = raw.strip()
         if line.startswith(";;#ASMSTART"):
@@ -45,6 +50,12 @@ def lint(asm_text):
         if op == "s_nop":
             slot += int(ops[0], 0) + 1
             continue
+        if "_load_lds_" in op or (op.startswith("buffer_load") and "lds" in ops):
+            n_dma += 1
+            if m0_written_asm is not None and slot - m0_written_asm - 1 < 1:
+                m0_bad.append((line, slot - m0_written_asm - 1))
+        if ops and ops[0] == "m0" and op.startswith("s_"):
+            m0_written_asm = slot if in_asm else None
         if op.startswith("v_mfma"):
             n_mfma += 1
             for tok in ops[1:3]:                                  # SrcA, SrcB
@@ -59,6 +70,8 @@ def lint(asm_text):
             for r in regs(ops[0]):
                 written.pop(r, None)
         slot += 1
+    if m0_report is not None:
+        m0_report.update(bad=m0_bad, n_dma=n_dma)
     return bad, n_prod, n_mfma
 
 
@@ -70,9 +83,12 @@ def test_no_asm_valu_result_is_read_by_an_mfma_too_early(name, tmp_path):
     r = subprocess.run([_build._hipcc(), *flags, "-S", "--cuda-device-only", str(src), "-o", str(out)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
-    bad, n_prod, n_mfma = lint(out.read_text())
+    m0 = {}
+    bad, n_prod, n_mfma = lint(out.read_text(), m0)
     assert n_prod >= 16 and n_mfma >= 64, (n_prod, n_mfma)        # the transform and the MFMA stream were really seen
     assert not bad, bad[:5]
+    assert m0["n_dma"] >= 6, m0                                   # the weight DMA was really seen
+    assert not m0["bad"], m0["bad"][:5]
 
 
 def test_lint_catches_the_hazard():
@@ -91,3 +107,26 @@ def test_lint_catches_the_hazard():
     bad, n_prod, n_mfma = lint(text)
     assert n_prod == 2 and n_mfma == 2
     assert len(bad) == 1 and bad[0][1] == 10 and bad[0][2] == 1
+
+
+def test_lint_catches_the_m0_hazard():
+    text = """
+	;;#ASMSTART
+	s_mov_b32 s5, m0
+	s_mov_b32 m0, s7
+	global_load_lds_dwordx4 v[2:3], off
+	s_mov_b32 m0, s5
+	;;#ASMEND
+	;;#ASMSTART
+	s_mov_b32 s5, m0
+	s_mov_b32 m0, s7
+	s_nop 0
+	global_load_lds_dwordx4 v[2:3], off
+	s_mov_b32 m0, s5
+	;;#ASMEND
+	s_mov_b32 m0, s9
+	global_load_lds_dwordx4 v[2:3], off
+"""
+    m0 = {}
+    lint(text, m0)
+    assert m0["n_dma"] == 3 and len(m0["bad"]) == 1 and m0["bad"][0][1] == 0

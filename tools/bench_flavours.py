@@ -34,7 +34,9 @@ def kernels(fn):
         fn()
     finally:
         KernelTimer.active = None
-    return {k: [v["launches"], round(v["total_ms"], 3), round(v["flops"] / max(v["total_ms"], 1e-9) / 1e9, 1)]
+    # tag -> [launches, ms, algorithmic TFLOP/s, TFLOP/s issued on the matrix pipe (Winograd: algorithmic / 2.25)]
+    return {k: [v["launches"], round(v["total_ms"], 3), round(v["flops"] / max(v["total_ms"], 1e-9) / 1e9, 1),
+                round(v["issued_flops"] / max(v["total_ms"], 1e-9) / 1e9, 1)]
             for k, v in kt.summary().items()}
 
 
@@ -136,7 +138,7 @@ def igev(b=4, h=96, w=312):
     return res
 
 
-def igev_model(b=4, h=384, w=1248, steps=20, iters=32):
+def igev_model(b=4, h=384, w=1248, steps=20, iters=32, quick=False):
     """BASELINE config 5 on one GPU: the IGEVStereo_ddim drop-in module end to end (stub MobileNetV2 backbone: timm's
     pretrained one does not exist offline), 1248x384, `steps` DDIM steps x `iters` GRU iterations, batch b."""
     import types
@@ -157,7 +159,17 @@ def igev_model(b=4, h=384, w=1248, steps=20, iters=32):
     flow_full = (9 + torch.randn(b, 1, h, w, generator=g)).clamp(0.5, 47).to(DEV)
     flow_gt = F.interpolate(flow_full, size=(h // 4, w // 4), mode="bilinear") / 4
     with torch.no_grad():
-        ms = timeit(lambda: m(img1, img2, flow_full, flow_gt, iters=iters, test_mode=True), warmup=1, steps=2)
+        if quick:       # bench.py extras: one short warm-up pass (2 GRU iterations per step), one timed full pass
+            m(img1, img2, flow_full, flow_gt, iters=2, test_mode=True)
+            ms = timeit(lambda: m(img1, img2, flow_full, flow_gt, iters=iters, test_mode=True), warmup=0, steps=1)
+            ks = kernels(lambda: m(img1, img2, flow_full, flow_gt, iters=2, test_mode=True))
+        else:
+            ms = timeit(lambda: m(img1, img2, flow_full, flow_gt, iters=iters, test_mode=True), warmup=1, steps=2)
+            ks = None
+    if ks is not None:
+        return {"config": f"KITTI15 IGEVStereo_ddim B={b} {w}x{h}, {steps} DDIM steps x {iters} GRU iterations (stub backbone)",
+                "forward_ms": ms, "pairs_per_s": b / (ms / 1e3), "ms_per_gru_iteration": ms / (steps * iters),
+                "kernels_of_a_2_iteration_pass": ks}
     return {"config": f"KITTI15 IGEVStereo_ddim B={b} {w}x{h}, {steps} DDIM steps x {iters} GRU iterations (stub backbone)",
             "forward_ms": ms, "pairs_per_s": b / (ms / 1e3), "ms_per_gru_iteration": ms / (steps * iters)}
 

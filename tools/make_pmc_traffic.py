@@ -10,6 +10,9 @@ import sys
 from pathlib import Path
 
 src, tag = Path(sys.argv[1]), sys.argv[2]
+head = sys.argv[3] if len(sys.argv) > 3 else None         # the GPU box has no .git: the caller passes the commit id
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from diffuvolume_amd._build import csrc_sha16  # noqa: E402
 dst = src / "summary"      # gpurun_out/ travels back from the GPU box; copy the files into profiles/ afterwards
 dst.mkdir(parents=True, exist_ok=True)
 
@@ -40,7 +43,8 @@ for k in sorted(fetch, key=lambda k: -sum(fetch[k])):
     kernels.append({"kernel": k, "launches": len(fetch[k]), "FETCH_SIZE_KB_raw": f_kb, "WRITE_SIZE_KB": w_kb,
                     "hbm_read_bytes_corrected": 2 * f_kb * 1024, "hbm_write_bytes": w_kb * 1024,
                     "hbm_bytes_per_launch": (2 * f_kb + w_kb) * 1024})
-out = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py "
+out = {"git_head": head, "csrc_sha16": csrc_sha16(),
+       "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py "
                   "--steps 1 --warmup 1 --no-cpu-baseline --no-extras --no-kernel-timer",
        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> x2 (MI355X_MICROARCH.md, HBM section); "
                      "check: gwc_rows_kernel 2*FETCH ~= 629 MB (its algorithmic input); WRITE_SIZE exact",

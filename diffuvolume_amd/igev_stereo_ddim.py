@@ -540,7 +540,8 @@ class IGEVStereo_ddim(nn.Module):
     """``IGEVStereo_ddim(args).forward(image1, image2, flow_full, flow_gt, iters=12, flow_init=None, test_mode=False)
     -> (pred, pred)`` (eval path, igev_stereo_ddim.py:361-427).  ``args``: hidden_dims, n_gru_layers, n_downsample,
     corr_levels, corr_radius, slow_fast_gru, max_disp, mixed_precision (must be False: the HIP path is fp32).
-    ``feature``: the MobileNetV2 feature pyramid (``Feature(backbone)``) -- required, see ``Feature``;
+    ``feature``: the MobileNetV2 feature pyramid (``Feature(backbone)``); None = the reference's own construction from
+    timm's pretrained ``mobilenetv2_100`` (core/extractor.py:327-335), which needs ``timm`` to be importable;
     ``cnet``: optional replacement for the context encoder.  ``sampling_timesteps`` / ``ensemble_cof`` are
     hard-coded to 2 / [0.6, 0.1, 0.3] in the reference (:124, :353); BASELINE config 5 asks for 20 steps."""
 
@@ -548,9 +549,17 @@ class IGEVStereo_ddim(nn.Module):
                  sampling_timesteps: int = 2, ensemble_cof: Optional[Sequence[float]] = None):
         super().__init__()
         if feature is None:
-            raise _lib.DiffuVolumeError(
-                "IGEVStereo_ddim needs feature=Feature(backbone): the reference builds it from timm's pretrained "
-                "mobilenetv2_100, which is not available offline (pass a timm model or synth.StubMobileNetV2())")
+            # the reference's own construction (core/extractor.py:327-335): timm's pretrained MobileNetV2, when timm exists
+            try:
+                import timm
+            except ImportError:
+                timm = None
+            if timm is None or not hasattr(timm, "create_model"):
+                raise _lib.DiffuVolumeError(
+                    "IGEVStereo_ddim(args) builds its feature pyramid from timm.create_model('mobilenetv2_100', "
+                    "pretrained=True, features_only=True) like the reference (core/extractor.py:331); timm is not "
+                    "importable here -- pass feature=Feature(backbone) (a timm model or synth.StubMobileNetV2())")
+            feature = Feature(timm.create_model("mobilenetv2_100", pretrained=True, features_only=True))
         if getattr(args, "mixed_precision", False):
             raise _lib.DiffuVolumeError("the HIP path computes in fp32: mixed_precision must be False")
         self.args = args

@@ -377,10 +377,11 @@ class _Plans:
         g = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float()
         self.du_a = (conv.weight.detach().float().reshape(-1) * g).contiguous()
         self.du_b = (bn.bias.detach().float() - bn.running_mean.detach().float() * g).contiguous()
-        ac = m.alphas_cumprod.detach().double().cpu()
-        self.alphas_cumprod = ac
-        self.sqrt_ac, self.sqrt_1mac = torch.sqrt(ac), torch.sqrt(1.0 - ac)
-        self.sqrt_recip, self.sqrt_recipm1 = torch.sqrt(1.0 / ac), torch.sqrt(1.0 / ac - 1)
+        if hasattr(m, "alphas_cumprod"):                                  # the origin network has no schedule
+            ac = m.alphas_cumprod.detach().double().cpu()
+            self.alphas_cumprod = ac
+            self.sqrt_ac, self.sqrt_1mac = torch.sqrt(ac), torch.sqrt(1.0 - ac)
+            self.sqrt_recip, self.sqrt_recipm1 = torch.sqrt(1.0 / ac), torch.sqrt(1.0 / ac - 1)
 
 
 def groupwise_corr_pm(ref: torch.Tensor, tgt: torch.Tensor, maxdisp: int) -> torch.Tensor:
@@ -399,81 +400,9 @@ def groupwise_corr_pm(ref: torch.Tensor, tgt: torch.Tensor, maxdisp: int) -> tor
     return out
 
 
-def warp(x: torch.Tensor, disp: torch.Tensor) -> torch.Tensor:
-    """warp(right, disp) (KITTI12/models/submodule.py:137-176): sample the right features at x - disp
-    (grid normalised with W-1 but sampled with grid_sample's default align_corners=False, as the
-    reference does) and zero everything the validity mask does not fully cover."""
-    b, c, h, w = x.shape
-    xx = torch.arange(0, w, device=x.device, dtype=torch.float32).view(1, 1, 1, w).expand(b, 1, h, w)
-    yy = torch.arange(0, h, device=x.device, dtype=torch.float32).view(1, 1, h, 1).expand(b, 1, h, w)
-    gx = 2.0 * (xx - disp) / max(w - 1, 1) - 1.0
-    gy = 2.0 * yy / max(h - 1, 1) - 1.0
-    grid = torch.cat((gx, gy), 1).permute(0, 2, 3, 1)
-    out = F.grid_sample(x, grid)
-    mask = F.grid_sample(torch.ones_like(x), grid)
-    mask = torch.where(mask < 0.999, torch.zeros_like(mask), torch.ones_like(mask))
-    return out * mask
-
-
-class PWCNet_ddim(nn.Module):
-    def __init__(self, maxdisp: int, use_concat_volume: bool = True, sampling_timesteps: int = 3,
-                 ensemble_cof: Optional[Sequence[float]] = None):
-        super().__init__()
-        if maxdisp != 192:
-            raise ValueError("PWCNet_ddim is defined for maxdisp == 192 (hard-coded 48 / 192 in the reference)")
-        self.maxdisp, self.use_concat_volume, self.num_groups = maxdisp, use_concat_volume, 40
-        self.scale, self.num_timesteps, self.sampling_timesteps = 1.0, 1000, sampling_timesteps
-        self.ddim_sampling_eta, self.renewal, self.use_ensemble = 1.0, True, True
-        if ensemble_cof is None:
-            if sampling_timesteps != 3:
-                raise ValueError("give ensemble_cof (S+1 weights) when sampling_timesteps != 3")
-            ensemble_cof = (0.9, 0.0, 0.0, 0.1)                       # pwcnet_ddim.py:599
-        if len(ensemble_cof) != sampling_timesteps + 1:
-            raise ValueError("ensemble_cof needs sampling_timesteps + 1 entries")
-        self.ensemble_cof = tuple(float(c) for c in ensemble_cof)
-        self.dif_threshold, self.unc_threshold = 1.0, 1.0            # :571-572 (the last step's <2 mask is unused)
-
-        betas = cosine_beta_schedule(self.num_timesteps)
-        alphas = 1.0 - betas
-        ac = torch.cumprod(alphas, dim=0)
-        ac_prev = F.pad(ac[:-1], (1, 0), value=1.0)
-        post_var = betas * (1.0 - ac_prev) / (1.0 - ac)
-        for name, val in (("betas", betas), ("alphas_cumprod", ac), ("alphas_cumprod_prev", ac_prev),
-                          ("sqrt_alphas_cumprod", torch.sqrt(ac)),
-                          ("sqrt_one_minus_alphas_cumprod", torch.sqrt(1.0 - ac)),
-                          ("log_one_minus_alphas_cumprod", torch.log(1.0 - ac)),
-                          ("sqrt_recip_alphas_cumprod", torch.sqrt(1.0 / ac)),
-                          ("sqrt_recipm1_alphas_cumprod", torch.sqrt(1.0 / ac - 1)),
-                          ("posterior_variance", post_var),
-                          ("posterior_log_variance_clipped", torch.log(post_var.clamp(min=1e-20))),
-                          ("posterior_mean_coef1", betas * torch.sqrt(ac_prev) / (1.0 - ac)),
-                          ("posterior_mean_coef2", (1.0 - ac_prev) * torch.sqrt(alphas) / (1.0 - ac))):
-            self.register_buffer(name, val)
-
-        self.concat_channels = 12 if use_concat_volume else 0
-        self.feature_extraction = FeatureExtraction(use_concat_volume, 12)
-        cin = self.num_groups + 2 * self.concat_channels
-        self.dres0 = nn.Sequential(_cb3(cin, 32, 3, 1, 1), Mish(), _cb3(32, 32, 3, 1, 1), Mish())
-        self.dres1 = nn.Sequential(_cb3(32, 32, 3, 1, 1), Mish(), _cb3(32, 32, 3, 1, 1))
-        self.combine1 = HourglassUp(32)
-        self.time_embedding = DynamicHead(d_model=48)
-        self.dres2, self.dres3, self.dres4 = Hourglass(32), Hourglass(32), Hourglass(32)
-        for i in range(5):
-            setattr(self, f"classif{i}", nn.Sequential(_cb3(32, 32, 3, 1, 1), Mish(), nn.Conv3d(32, 1, 3, 1, 1, bias=False)))
-        self.refinenet3 = RefineNet(146)
-        self.dispupsample = nn.Sequential(_cb2(1, 32, 1, 1, 0, 1), Mish())
-        for m in self.modules():                                     # pwcnet_ddim.py:433-447
-            if isinstance(m, (nn.Conv2d, nn.Conv3d)) and not isinstance(m, nn.ConvTranspose3d):
-                n = m.out_channels
-                for k in m.kernel_size:
-                    n *= k
-                m.weight.data.normal_(0, math.sqrt(2.0 / n))
-            elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d)):
-                m.weight.data.fill_(1)
-                m.bias.data.zero_()
-            elif isinstance(m, nn.Linear):
-                m.bias.data.zero_()
-        self._plans: Optional[_Plans] = None
+class _PWCCommon:
+    """What the origin network (`PWCNet`, pwcnet.py:310-507) and `PWCNet_ddim` share: the plan cache, the fused
+    multi-scale volume and the 2-D refinement of a regressed disparity."""
 
     # ---- plan cache ---------------------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
@@ -509,6 +438,144 @@ class PWCNet_ddim(nn.Module):
                 self._plans.weights_version = self._weights_version()
                 self._plans.loop_key = self._plans.loop_steps = None
         return self._plans
+
+    @torch.no_grad()
+    def fused_volume(self, fl, fr):
+        """pwcnet_ddim.py:608-641: four gwc(+concat) volumes -> dres0/dres1 -> hourglassup -> `combine`."""
+        p = self.prepare()
+        vols = []
+        for i, div in enumerate((4, 8, 16, 32), start=1):
+            v = build_gwc_volume(fl[f"gw{i}"], fr[f"gw{i}"], self.maxdisp // div, self.num_groups)
+            if self.use_concat_volume:
+                cv = build_concat_volume(fl[f"concat_feature{i}"], fr[f"concat_feature{i}"], self.maxdisp // div,
+                                         zero_left=True)
+                v = torch.cat((v, cv), 1)
+            vols.append(v)
+        cost0 = p.dres0(vols[0])
+        cost0 = p.dres1(cost0, residual_self=True)
+        return p.combine1(cost0, vols[1], vols[2], vols[3])
+
+    def _init_backbone(self, use_concat_volume: bool, time_embedding: bool):
+        """Sub-modules under the reference's attribute names, in its construction order (pwcnet.py:318-362,
+        pwcnet_ddim.py:389-431), and its weight initialisation (:364-381 / :433-447)."""
+        self.concat_channels = 12 if use_concat_volume else 0
+        self.feature_extraction = FeatureExtraction(use_concat_volume, 12)
+        cin = self.num_groups + 2 * self.concat_channels
+        self.dres0 = nn.Sequential(_cb3(cin, 32, 3, 1, 1), Mish(), _cb3(32, 32, 3, 1, 1), Mish())
+        self.dres1 = nn.Sequential(_cb3(32, 32, 3, 1, 1), Mish(), _cb3(32, 32, 3, 1, 1))
+        self.combine1 = HourglassUp(32)
+        if time_embedding:
+            self.time_embedding = DynamicHead(d_model=48)
+        self.dres2, self.dres3, self.dres4 = Hourglass(32), Hourglass(32), Hourglass(32)
+        for i in range(5):
+            setattr(self, f"classif{i}", nn.Sequential(_cb3(32, 32, 3, 1, 1), Mish(), nn.Conv3d(32, 1, 3, 1, 1, bias=False)))
+        self.refinenet3 = RefineNet(146)
+        self.dispupsample = nn.Sequential(_cb2(1, 32, 1, 1, 0, 1), Mish())
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.Conv3d)) and not isinstance(m, nn.ConvTranspose3d):
+                n = m.out_channels
+                for k in m.kernel_size:
+                    n *= k
+                m.weight.data.normal_(0, math.sqrt(2.0 / n))
+            elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d)):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+            elif isinstance(m, nn.Linear):
+                m.bias.data.zero_()
+        self._plans: Optional[_Plans] = None
+
+    @staticmethod
+    def refine_features(features_left, features_right, size):
+        """pwcnet_ddim.py:487-492 / pwcnet.py:481-486: both `finetune_feature` maps resized to full resolution
+        (bilinear, align_corners=True).  They do not depend on the DDIM step: `ddim_sample` resizes them once per
+        call instead of once per step."""
+        hh, ww = size
+        fl = F.interpolate(features_left["finetune_feature"], [hh, ww], mode="bilinear", align_corners=True)
+        fr = F.interpolate(features_right["finetune_feature"], [hh, ww], mode="bilinear", align_corners=True)
+        return fl, fr
+
+    def _refine(self, pred3, features_left, features_right, resized=None):
+        """pwcnet_ddim.py:486-502: warp the right refinement feature by pred3, +-24 correlation, concat
+        (one HIP kernel), refinenet3 (2-D implicit-GEMM kernel) -> disp_finetune [B,H,W].  ``resized``: the two
+        full-resolution feature maps of `refine_features` when the caller already has them."""
+        p3 = pred3.unsqueeze(1)
+        fl, fr = resized if resized is not None else self.refine_features(features_left, features_right, pred3.shape[-2:])
+        plans = self.prepare()
+        comb = refine_inputs(fl, fr, p3, plans.du_a, plans.du_b, 24)      # warp, +-24 correlation, concat
+        return plans.refinenet3(comb, p3.contiguous()).squeeze(1)
+
+
+class PWCNet(_PWCCommon, nn.Module):
+    """The origin PCWNet of KITTI12/models/pwcnet.py:310-507 (`gwcnet-g` / `gwcnet-gc` in the registry,
+    models/__init__.py:5-9) -- the network whose output is the `used` disparity of KITTI12/test.py:86-92 -- on the
+    same kernels as `PWCNet_ddim`: eval ``forward(left, right) -> ([disp_finetune], [pred3])`` (:483-507).  Same
+    parameter names and shapes as the reference class (no time embedding, no schedule buffers)."""
+
+    def __init__(self, maxdisp: int, use_concat_volume: bool = False):
+        super().__init__()
+        if maxdisp != 192:
+            raise ValueError("PWCNet is defined for maxdisp == 192 here (the volume pyramid divides it by 4..32)")
+        self.maxdisp, self.use_concat_volume, self.num_groups = maxdisp, use_concat_volume, 40
+        self._init_backbone(use_concat_volume, time_embedding=False)
+
+    def forward(self, left, right):
+        if self.training:
+            raise NotImplementedError("the MI355X DiffuVolume path is inference-only (model.eval())")
+        with torch.no_grad():
+            p = self.prepare(check_weights=True)
+            fl = self.feature_extraction(left)
+            fr = self.feature_extraction(right)
+            combine = self.fused_volume(fl, fr)
+            cost3 = p.classif3(p.dres4(p.dres3(p.dres2(combine))))            # pwcnet.py:421-424, :469
+            pred3, _ = upsample_softmax_regress(cost3, want_uncertainty=False, align_corners=True)
+            disp_finetune = self._refine(pred3, fl, fr)
+        return [disp_finetune], [pred3]
+
+
+def PWCNet_G(d):
+    return PWCNet(d, use_concat_volume=False)
+
+
+def PWCNet_GC(d):
+    return PWCNet(d, use_concat_volume=True)
+
+
+class PWCNet_ddim(_PWCCommon, nn.Module):
+    def __init__(self, maxdisp: int, use_concat_volume: bool = True, sampling_timesteps: int = 3,
+                 ensemble_cof: Optional[Sequence[float]] = None):
+        super().__init__()
+        if maxdisp != 192:
+            raise ValueError("PWCNet_ddim is defined for maxdisp == 192 (hard-coded 48 / 192 in the reference)")
+        self.maxdisp, self.use_concat_volume, self.num_groups = maxdisp, use_concat_volume, 40
+        self.scale, self.num_timesteps, self.sampling_timesteps = 1.0, 1000, sampling_timesteps
+        self.ddim_sampling_eta, self.renewal, self.use_ensemble = 1.0, True, True
+        if ensemble_cof is None:
+            if sampling_timesteps != 3:
+                raise ValueError("give ensemble_cof (S+1 weights) when sampling_timesteps != 3")
+            ensemble_cof = (0.9, 0.0, 0.0, 0.1)                       # pwcnet_ddim.py:599
+        if len(ensemble_cof) != sampling_timesteps + 1:
+            raise ValueError("ensemble_cof needs sampling_timesteps + 1 entries")
+        self.ensemble_cof = tuple(float(c) for c in ensemble_cof)
+        self.dif_threshold, self.unc_threshold = 1.0, 1.0            # :571-572 (the last step's <2 mask is unused)
+
+        betas = cosine_beta_schedule(self.num_timesteps)
+        alphas = 1.0 - betas
+        ac = torch.cumprod(alphas, dim=0)
+        ac_prev = F.pad(ac[:-1], (1, 0), value=1.0)
+        post_var = betas * (1.0 - ac_prev) / (1.0 - ac)
+        for name, val in (("betas", betas), ("alphas_cumprod", ac), ("alphas_cumprod_prev", ac_prev),
+                          ("sqrt_alphas_cumprod", torch.sqrt(ac)),
+                          ("sqrt_one_minus_alphas_cumprod", torch.sqrt(1.0 - ac)),
+                          ("log_one_minus_alphas_cumprod", torch.log(1.0 - ac)),
+                          ("sqrt_recip_alphas_cumprod", torch.sqrt(1.0 / ac)),
+                          ("sqrt_recipm1_alphas_cumprod", torch.sqrt(1.0 / ac - 1)),
+                          ("posterior_variance", post_var),
+                          ("posterior_log_variance_clipped", torch.log(post_var.clamp(min=1e-20))),
+                          ("posterior_mean_coef1", betas * torch.sqrt(ac_prev) / (1.0 - ac)),
+                          ("posterior_mean_coef2", (1.0 - ac_prev) * torch.sqrt(alphas) / (1.0 - ac))):
+            self.register_buffer(name, val)
+
+        self._init_backbone(use_concat_volume, time_embedding=True)
 
     def _loop_plan(self):
         """Per-step constants of the loop (time-MLP shift on the device, coefficient struct): they depend only
@@ -554,18 +621,6 @@ class PWCNet_ddim(nn.Module):
         p = self.prepare()
         return p.classif3(p.dres4(p.dres3(p.dres2(volume, in_scale=n01f))))
 
-    def _refine(self, pred3, features_left, features_right):
-        """pwcnet_ddim.py:486-502: warp the right refinement feature by pred3, +-24 correlation, concat
-        (one HIP kernel), refinenet3 (2-D implicit-GEMM kernel) -> disp_finetune [B,H,W].  The module-level
-        ``warp`` / ``groupwise_corr_pm`` are the PyTorch statement of the same input assembly."""
-        hh, ww = pred3.shape[-2:]
-        p3 = pred3.unsqueeze(1)
-        fl = F.interpolate(features_left["finetune_feature"], [hh, ww], mode="bilinear", align_corners=True)
-        fr = F.interpolate(features_right["finetune_feature"], [hh, ww], mode="bilinear", align_corners=True)
-        plans = self.prepare()
-        comb = refine_inputs(fl, fr, p3, plans.du_a, plans.du_b, 24)      # warp, +-24 correlation, concat
-        return plans.refinenet3(comb, p3.contiguous()).squeeze(1)
-
     def _uncertainty_about(self, cost, disp):
         """sum_k |disp - k| * softmax(upsampled cost)_k with ``disp`` = the refined disparity (:548-552)."""
         cost = cost[:, 0] if cost.dim() == 5 else cost
@@ -609,11 +664,11 @@ class PWCNet_ddim(nn.Module):
                                             b, c, h, w, ctypes.byref(coef), _lib.stream_ptr()), "dv_ddim_step")
         return x_start, x_next, pred_noise
 
-    def _predict(self, volume, img, t, features_left, features_right, shift=None):
+    def _predict(self, volume, img, t, features_left, features_right, shift=None, resized=None):
         n01, n01f = self._filter(img, t, shift)
         cost = self._aggregate(volume, n01f)
         pred3, _ = upsample_softmax_regress(cost, want_uncertainty=False, align_corners=True)
-        disp = self._refine(pred3, features_left, features_right).contiguous()
+        disp = self._refine(pred3, features_left, features_right, resized).contiguous()
         unc = self._uncertainty_about(cost, disp)
         return n01, cost, disp, unc
 
@@ -662,6 +717,9 @@ class PWCNet_ddim(nn.Module):
             mask = torch.zeros((b, h, w), dtype=torch.float32, device=dev)
             ens = used * self.ensemble_cof[0]
             handle = None
+            # step-invariant: the two refinement feature maps at full resolution (the reference resizes them inside
+            # every model_predictions call, :487-492)
+            resized = self.refine_features(features_left, features_right, (4 * h, 4 * w))
             for i, st in enumerate(self._loop_plan()):
                 time, time_next = st.time, st.time_next
                 eps = fill = None
@@ -674,7 +732,8 @@ class PWCNet_ddim(nn.Module):
                     trace(i, {"when": "in", "img": img, "mask": mask.clone(), "eps": eps, "fill": fill})
                 # (the last step's mask is never read again: the reference only builds the unused mask_final there)
                 disp, unc, x_start, x_next, cost = self.ddim_step(i, volume, used, img, mask, ens, eps, fill,
-                                                                  features_left, features_right, want_cost=True)
+                                                                  features_left, features_right, want_cost=True,
+                                                                  resized=resized)
                 if trace is not None:
                     trace(i, {"when": "out", "disp": disp, "unc": unc, "x_start": x_start, "x_next": x_next,
                               "mask": mask.clone()})
@@ -689,13 +748,13 @@ class PWCNet_ddim(nn.Module):
 
     @torch.no_grad()
     def ddim_step(self, i, volume, used, img, mask, ens=None, eps=None, fill=None, features_left=None,
-                  features_right=None, want_cost=False):
+                  features_right=None, want_cost=False, resized=None):
         """Iteration ``i`` of the loop of pwcnet_ddim.py:545-598 from explicit state (``img`` entering the step,
         ``mask`` updated in place, ``eps`` = randn_like(img), ``fill`` = the q_sample'd origin encoding).
         Returns (disp_finetune [B,4h,4w], uncertainty, x_start fp32, x_next fp64 | None[, cost])."""
         st = self._loop_plan()[i]
         n01, cost, disp, unc = self._predict(volume, img, None, features_left, features_right,
-                                             shift=st.shift_rows(volume.shape[0]))
+                                             shift=st.shift_rows(volume.shape[0]), resized=resized)
         x_start, x_next, _ = self._ddim_update(disp, unc, used, n01, eps, fill, mask, ens, st.coef)
         return (disp, unc, x_start, x_next, cost) if want_cost else (disp, unc, x_start, x_next)
 
@@ -708,22 +767,6 @@ class PWCNet_ddim(nn.Module):
             _lib.check(_lib.load().dv_encode_two_hot_f32(disp.data_ptr(), x.data_ptr(), b, 48, h * w,
                                                          _lib.stream_ptr()), "dv_encode_two_hot_f32")
         return x
-
-    @torch.no_grad()
-    def fused_volume(self, fl, fr):
-        """pwcnet_ddim.py:608-641: four gwc(+concat) volumes -> dres0/dres1 -> hourglassup -> `combine`."""
-        p = self.prepare()
-        vols = []
-        for i, div in enumerate((4, 8, 16, 32), start=1):
-            v = build_gwc_volume(fl[f"gw{i}"], fr[f"gw{i}"], self.maxdisp // div, self.num_groups)
-            if self.use_concat_volume:
-                cv = build_concat_volume(fl[f"concat_feature{i}"], fr[f"concat_feature{i}"], self.maxdisp // div,
-                                         zero_left=True)
-                v = torch.cat((v, cv), 1)
-            vols.append(v)
-        cost0 = p.dres0(vols[0])
-        cost0 = p.dres1(cost0, residual_self=True)
-        return p.combine1(cost0, vols[1], vols[2], vols[3])
 
     def forward(self, left, right, used, disp, mask=None):
         if self.training:

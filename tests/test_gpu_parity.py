@@ -780,20 +780,18 @@ def test_conv2d_stride2_oracle(cfg):
     assert out.shape == y.shape and rel_err(out, y) < 1e-5
 
 
-def test_feature_cnn_on_hip_matches_the_pytorch_modules():
-    """FeatureExtraction (acv_ddim.py:14-53) through the fused 2-D kernel vs the same nn.Modules run by PyTorch."""
+def test_feature_cnn_matches_the_reference_class():
+    """FeatureExtraction (acv_ddim.py:14-53) through the fused 2-D kernels against the output of the REFERENCE's
+    `feature_extraction` on the same weights and image (tests/golden/feature_cnns.npz, oracle/make_golden_features.py)."""
     import diffuvolume_amd as dv
-    m = dv.ACVNet_DDIM(192, False, False)
-    m.load_state_dict(synth_state_dict(m.state_dict(), seed=5), strict=True)
-    fe = m.feature_extraction.to(DEV).eval()
-    x = torch.randn(2, 3, 64, 160, generator=_gen(71, "img")).to(DEV)
+    g = load_golden("feature_cnns")
+    fe = dv.ACVNet_DDIM(192, False, False).feature_extraction
+    fe.load_state_dict(synth_state_dict(fe.state_dict(), seed=g["seed"]), strict=True)
+    fe = fe.to(DEV).eval()
     with torch.no_grad():
-        y = fe(x)["gwc_feature"]
-        t = fe.layer1(fe.firstconv(x))
-        l2 = fe.layer2(t); l3 = fe.layer3(l2); l4 = fe.layer4(l3)
-        ref = torch.cat((l2, l3, l4), dim=1)
-    assert y.shape == ref.shape == (2, 320, 16, 40)
-    assert rel_err(y, ref.cpu()) < 2e-5
+        y = fe(dev(g["x"]))["gwc_feature"]
+    assert y.shape == g["acv_gwc_feature"].shape == (1, 320, 8, 16)
+    assert rel_err(y, g["acv_gwc_feature"]) < 2e-5
 
 
 @pytest.mark.parametrize("shape", [(1, 40, 3, 20, 140), (2, 40, 2, 33, 50)])

@@ -178,13 +178,64 @@ def test_refine_inputs_vs_oracle(shape):
     torch.testing.assert_close(out.cpu(), ref, atol=2e-5, rtol=1e-5)
 
 
-def test_feature_cnn_on_hip_matches_the_pytorch_modules(model):
-    """The multi-scale feature CNN (pwcnet_ddim.py:12-128) on the fused 2-D kernel vs the same nn.Modules in PyTorch."""
-    fe = model.feature_extraction
-    x = torch.randn(1, 3, 64, 160, generator=_gen(91, "img")).to(DEV) * 0.05
+def test_feature_cnn_matches_the_reference_class():
+    """The multi-scale feature CNN (pwcnet_ddim.py:12-128) on the fused 2-D kernels against the outputs of the
+    REFERENCE's `feature_extraction(concat_feature=True)` on the same weights and image (tests/golden/feature_cnns.npz,
+    oracle/make_golden_features.py) -- all nine heads."""
+    from diffuvolume_amd.pwcnet_ddim import FeatureExtraction
+    g = load_golden("feature_cnns")
+    fe = FeatureExtraction(True, 12)
+    fe.load_state_dict(synth_state_dict(fe.state_dict(), seed=g["seed"]), strict=True)
+    fe = fe.to(DEV).eval()
     with torch.no_grad():
-        got, ref = fe(x), fe._forward_modules(x)
-    assert set(got) == set(ref)
-    for k in ref:
-        assert got[k].shape == ref[k].shape
-        assert rel_err(got[k], ref[k].cpu()) < 5e-5, k
+        got = fe(dev(g["x"]))
+    heads = [k[4:] for k in g if k.startswith("pcw_")]
+    assert set(got) == set(heads) and len(heads) == 9
+    for k in heads:
+        assert got[k].shape == g["pcw_" + k].shape
+        assert rel_err(got[k], g["pcw_" + k]) < 5e-5, k
+
+
+def test_origin_pcwnet_forward_matches_the_reference_class():
+    """`gwcnet-gc` (KITTI12/models/__init__.py:5-9): the ORIGIN PCWNet -- the network that supplies `used` in
+    KITTI12/test.py:86-92 -- on the same kernels; golden = the reference class's eval forward (pwcnet.py:468-507) on a
+    64x128 pair, state_dict keys checked one by one in the generator (oracle/make_golden_pcw_origin.py)."""
+    import diffuvolume_amd as dv
+    g = load_golden("pcw_origin_forward")
+    scale = {str(k): float(v) for k, v in zip(g["gwcnet_gc_scale_keys"].tolist(), g["gwcnet_gc_scale_vals"].tolist())}
+    m = dv.__models__["gwcnet-gc"](192)
+    sd = m.state_dict()
+    assert len(sd) == g["gwcnet_gc_n_keys"]
+    assert not any(k.startswith(("time_embedding", "alphas", "betas", "sqrt_", "posterior")) for k in sd)
+    m.load_state_dict(synth_state_dict(sd, seed=4, logit_gain=8.0, scale=scale), strict=True)
+    m = m.to(DEV).eval()
+    batch = synth_stereo_batch(1, 64, 128, seed=g["stereo_seed"], shifts=(8,))
+    fin, p3 = m(dev(batch["left"]), dev(batch["right"]))
+    assert len(fin) == 1 and len(p3) == 1 and fin[0].shape == (1, 64, 128)
+    d3 = (p3[0].cpu() - g["gwcnet_gc_pred3"]).abs()
+    df = (fin[0].cpu() - g["gwcnet_gc_disp_finetune"]).abs()
+    # the contract's bars (1e-3 px on 99.9 % of the pixels, EPE 1e-4) on both outputs
+    assert float((d3 > 1e-3).float().mean()) <= 1e-3 and float(d3.mean()) < 1e-4, (float(d3.mean()), float(d3.max()))
+    assert float((df > 1e-3).float().mean()) <= 1e-3 and float(df.mean()) < 1e-4, (float(df.mean()), float(df.max()))
+    # test_sample of KITTI12/test.py:86-92 end to end: origin -> used -> quarter-resolution encoding input -> DiffuVolume
+    ddim = dv.__models__["pwc_ddimgc"](192)
+    ddim.load_state_dict(synth_state_dict(ddim.state_dict(), seed=2, logit_gain=8.0, scale=scale), strict=True)
+    ddim = ddim.to(DEV).eval()
+    used = fin[0]
+    dq = torch.nn.functional.interpolate(torch.clamp(used, 0, 191).unsqueeze(1), size=(16, 32), mode="bilinear") / 4
+    out, _ = ddim(dev(batch["left"]), dev(batch["right"]), used, dq)
+    assert out[0].shape == (1, 64, 128) and bool(torch.isfinite(out[0]).all())
+
+
+def test_gwcnet_g_is_registered_and_fails_like_the_reference():
+    """`gwcnet-g` (no concat volume) exists in the reference's registry but its forward cannot run there: `hourglassup`
+    is built for 64-channel volumes (pwcnet.py:137-160).  Same keys, same failure here (recorded in the golden)."""
+    import diffuvolume_amd as dv
+    g = load_golden("pcw_origin_forward")
+    m = dv.__models__["gwcnet-g"](192)
+    assert len(m.state_dict()) == g["gwcnet_g_n_keys"]
+    m = m.to(DEV).eval()
+    batch = synth_stereo_batch(1, 64, 128, seed=g["stereo_seed"], shifts=(8,))
+    assert str(g["gwcnet_g_forward_error"]) == "RuntimeError"
+    with pytest.raises((RuntimeError, KeyError)):
+        m(dev(batch["left"]), dev(batch["right"]))

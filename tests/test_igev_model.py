@@ -46,8 +46,29 @@ def test_state_dict_layout_and_contract():
         assert k in sd, k
     assert sd["alphas_cumprod"].dtype == torch.float64
     m.load_state_dict(synth_state_dict(sd, seed=3), strict=True)
-    with pytest.raises(_lib.DiffuVolumeError, match="feature="):
-        IGEVStereo_ddim(types.SimpleNamespace(**ARGS))
+    # IGEVStereo_ddim(args) as the reference constructs it (core/igev_stereo_ddim.py:118-121, extractor.py:331): the
+    # backbone comes from timm when timm is importable, and only otherwise is feature= asked for
+    import sys
+    had = sys.modules.get("timm")
+    try:
+        sys.modules["timm"] = None                                    # import timm -> ImportError
+        with pytest.raises(_lib.DiffuVolumeError, match="feature="):
+            IGEVStereo_ddim(types.SimpleNamespace(**ARGS))
+        calls = []
+
+        def create_model(name, pretrained=False, features_only=False):
+            calls.append((name, pretrained, features_only))
+            return StubMobileNetV2()
+
+        sys.modules["timm"] = types.SimpleNamespace(create_model=create_model)
+        m2 = IGEVStereo_ddim(types.SimpleNamespace(**ARGS))
+        assert calls == [("mobilenetv2_100", True, True)]
+        assert list(m2.state_dict().keys()) == list(sd.keys())
+    finally:
+        if had is None:
+            sys.modules.pop("timm", None)
+        else:
+            sys.modules["timm"] = had
     with pytest.raises(ValueError):
         build(steps=20)                                              # ensemble weights must be given for S != 2
     m.train()

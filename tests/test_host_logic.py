@@ -148,4 +148,6 @@ def test_origin_and_pcw_state_dict_layouts():
     assert len(sd) == 905 and sum(p.numel() for p in pcw.parameters()) == 35994800
     assert tuple(sd["combine1.conv7.0.weight"].shape) == (128, 128, 3, 3, 3)
     assert pcw._time_pairs() == [(999, 665), (665, 332), (332, -1)]
-    assert sorted(__models__) == ["acvnet", "acvnet_ddim", "pwc_ddimgc"]
+    # SceneFlow/models/__init__.py + KITTI12/models/__init__.py:5-9
+    assert sorted(__models__) == ["acvnet", "acvnet_ddim", "gwcnet-g", "gwcnet-gc", "pwc_ddimgc"]
+    assert len(__models__["gwcnet-gc"](192).state_dict()) == 887 and len(__models__["gwcnet-g"](192).state_dict()) == 859

@@ -27,7 +27,7 @@ from torch import nn
 
 from . import _lib
 from .head import DynamicHead
-from .submodule import (ACT_NONE, ACT_RELU, Conv2dPlan, Conv3dPlan, Deconv3dPlan, _dev_f32,
+from .submodule import (ACT_NONE, ACT_RELU, Conv2dPlan, Conv3dPlan, Deconv3dPlan, ReplicaPlanCache, _dev_f32,
                         build_concat_attention_volume, build_gwc_volume, check_split_overflow,
                         default_conv_precision, patch_volume, upsample_softmax_regress, window_attention)
 
@@ -84,7 +84,7 @@ class _ResBlock2dPlan:
         return self.conv2(self.conv1(x), residual=x if self.down is None else self.down(x))
 
 
-class FeatureExtraction(nn.Module):
+class FeatureExtraction(ReplicaPlanCache, nn.Module):
     """2-D feature CNN (acv_ddim.py:14-53): 320-channel 1/4-resolution ``gwc_feature``.  On the GPU (eval) all 55
     convolutions run on the 2-D implicit-GEMM kernel with BN / ReLU / the residual add fused (csrc/conv2d.hip)."""
 
@@ -111,31 +111,38 @@ class FeatureExtraction(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._plans = None
+        self._replica_clear()
         return super()._apply(fn, *a, **k)
 
     def _load_from_state_dict(self, *a, **k):
         self._plans = None
+        self._replica_clear()
         return super()._load_from_state_dict(*a, **k)
 
     def train(self, mode: bool = True):
         if mode != self.training:
             self._plans = None
+            self._replica_clear()
         return super().train(mode)
 
     def _replicate_for_data_parallel(self):
         replica = super()._replicate_for_data_parallel()
         replica._plans = None
-        return replica
+        return self._mark_replica(replica)
 
     def prepare(self):
         version = sum(t._version for t in self.parameters()) + sum(t._version for t in self.buffers())
         if self._plans is not None and self._plans[2] != version:      # weights overwritten in place since
             self._plans = None
         if self._plans is None:
+            dev = self.firstconv[0][0].weight.device
+            self._plans = self._replica_lookup(dev)                      # nn.DataParallel replica: plans parked on the source
+        if self._plans is None:
             with torch.no_grad():
                 first = [_plan_cb2(self.firstconv[i], ACT_RELU) for i in (0, 2, 4)]
                 stacks = [[_ResBlock2dPlan(b) for b in getattr(self, n)] for n in ("layer1", "layer2", "layer3", "layer4")]
             self._plans = (first, stacks, version)
+            self._replica_store(dev, self._plans)
         return self._plans
 
     def forward(self, x):
@@ -303,7 +310,7 @@ def cosine_beta_schedule(timesteps: int, s: float = 0.008) -> torch.Tensor:
     return torch.clip(1 - (ac[1:] / ac[:-1]), 0, 0.999)
 
 
-class _HipPlanMixin(nn.Module):
+class _HipPlanMixin(ReplicaPlanCache, nn.Module):
     """Plan cache shared by the ACV wrappers: BatchNorm folding / weight repacking happens once per weight
     set and is redone when parameters move, are reloaded (through this module or any wrapper: ``nn.DataParallel(
     model).load_state_dict`` only reaches ``_load_from_state_dict``) or the train/eval mode really changes."""
@@ -311,6 +318,7 @@ class _HipPlanMixin(nn.Module):
 
     def _drop_plans(self):
         self._plans = None
+        self._replica_clear()
 
     def _apply(self, fn, *args, **kwargs):
         self._drop_plans()
@@ -330,7 +338,7 @@ class _HipPlanMixin(nn.Module):
         (broadcast) weights on its own device, not inherit the source module's device-resident plans."""
         replica = super()._replicate_for_data_parallel()
         replica._plans = None
-        return replica
+        return self._mark_replica(replica)
 
     def _weights_version(self) -> int:
         """Sum of the in-place version counters of every parameter and buffer: changes whenever a weight is
@@ -347,9 +355,14 @@ class _HipPlanMixin(nn.Module):
             if dev.type != "cuda":
                 raise _lib.DiffuVolumeError(
                     "the ACVNet hot path needs the model on the MI355X (model.cuda()); no CPU fallback")
+            self._plans = self._replica_lookup(dev)          # nn.DataParallel replica: plans parked on the source module
+            if self._plans is not None:
+                self._plans.weights_version = self._weights_version()
+                return self._plans
             with torch.no_grad(), torch.cuda.device(dev):
                 self._plans = _Plans(self)
                 self._plans.weights_version = self._weights_version()
+            self._replica_store(dev, self._plans)
         return self._plans
 
 

@@ -30,7 +30,7 @@ from . import _lib
 from .acv_ddim import ProbVolumeHandle, _LoopStep, _bn_of, _plan_cb3, cosine_beta_schedule
 from .head import DynamicHead
 from .profiling import timed
-from .submodule import (ACT_MISH, ACT_NONE, Conv2dPlan, Conv3dPlan, Deconv3dPlan, _dev_f32, build_concat_volume,
+from .submodule import (ACT_MISH, ACT_NONE, Conv2dPlan, Conv3dPlan, Deconv3dPlan, ReplicaPlanCache, _dev_f32, build_concat_volume,
                         build_gwc_volume, check_split_overflow, refine_inputs, upsample_softmax_regress)
 
 NoiseFn = Callable[[str, Tuple[int, ...], torch.dtype], torch.Tensor]
@@ -83,7 +83,7 @@ def _head2d(cin, mid, cout):
     return nn.Sequential(_cb2(cin, mid, 3, 1, 1, 1), Mish(), nn.Conv2d(mid, cout, 1, bias=False))
 
 
-class FeatureExtraction(nn.Module, _Stacker):
+class FeatureExtraction(ReplicaPlanCache, nn.Module, _Stacker):
     """Multi-scale 2-D feature CNN (pwcnet_ddim.py:12-128): gw1..gw4 at 1/4..1/32, concat features,
     refinement feature.  On the GPU (eval) every convolution runs on the 2-D HIP kernel."""
 
@@ -116,26 +116,32 @@ class FeatureExtraction(nn.Module, _Stacker):
 
     def _apply(self, fn, *a, **k):
         self._plans = None
+        self._replica_clear()
         return super()._apply(fn, *a, **k)
 
     def _load_from_state_dict(self, *a, **k):
         self._plans = None
+        self._replica_clear()
         return super()._load_from_state_dict(*a, **k)
 
-    def _replicate_for_data_parallel(self):        # nn.DataParallel replicas fold / pack their own weights
+    def _replicate_for_data_parallel(self):        # nn.DataParallel replicas: plans parked on the source, per device
         replica = super()._replicate_for_data_parallel()
         replica._plans = None
-        return replica
+        return self._mark_replica(replica)
 
     def train(self, mode: bool = True):
         if mode != self.training:
             self._plans = None
+            self._replica_clear()
         return super().train(mode)
 
     def prepare(self):
         version = sum(t._version for t in self.parameters()) + sum(t._version for t in self.buffers())
         if self._plans is not None and self._plans.get("version") != version:      # weights overwritten in place since
             self._plans = None
+        if self._plans is None:
+            dev = self.firstconv[0][0].weight.device
+            self._plans = self._replica_lookup(dev)
         if self._plans is None:
             def head(seq):          # convbn + Mish + Conv2d 1x1
                 return (_plan_cb2(seq[0], ACT_MISH), Conv2dPlan(seq[2].weight, None, act=ACT_NONE))
@@ -148,6 +154,7 @@ class FeatureExtraction(nn.Module, _Stacker):
                 p["refine"] = (_plan_cb2(self.layer_refine[0], ACT_MISH), _plan_cb2(self.layer_refine[2], ACT_MISH))
             p["version"] = version
             self._plans = p
+            self._replica_store(dev, p)
         return self._plans
 
     def forward(self, x):
@@ -400,27 +407,30 @@ def groupwise_corr_pm(ref: torch.Tensor, tgt: torch.Tensor, maxdisp: int) -> tor
     return out
 
 
-class _PWCCommon:
+class _PWCCommon(ReplicaPlanCache):
     """What the origin network (`PWCNet`, pwcnet.py:310-507) and `PWCNet_ddim` share: the plan cache, the fused
     multi-scale volume and the 2-D refinement of a regressed disparity."""
 
     # ---- plan cache ---------------------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
         self._plans = None
+        self._replica_clear()
         return super()._apply(fn, *a, **k)
 
     def _load_from_state_dict(self, *a, **k):      # reached however the checkpoint arrives (wrapper or direct)
         self._plans = None
+        self._replica_clear()
         return super()._load_from_state_dict(*a, **k)
 
-    def _replicate_for_data_parallel(self):        # nn.DataParallel replicas fold / pack their own weights
+    def _replicate_for_data_parallel(self):        # nn.DataParallel replicas: plans parked on the source, per device
         replica = super()._replicate_for_data_parallel()
         replica._plans = None
-        return replica
+        return self._mark_replica(replica)
 
     def train(self, mode: bool = True):
         if mode != self.training:
             self._plans = None
+            self._replica_clear()
         return super().train(mode)
 
     def _weights_version(self) -> int:
@@ -433,10 +443,15 @@ class _PWCCommon:
             dev = self.dres0[0][0].weight.device
             if dev.type != "cuda":
                 raise _lib.DiffuVolumeError("PWCNet_ddim hot path needs the model on the MI355X; no CPU fallback")
+            self._plans = self._replica_lookup(dev)          # nn.DataParallel replica: plans parked on the source module
+            if self._plans is not None:
+                self._plans.weights_version = self._weights_version()
+                return self._plans
             with torch.no_grad(), torch.cuda.device(dev):
                 self._plans = _Plans(self)
                 self._plans.weights_version = self._weights_version()
                 self._plans.loop_key = self._plans.loop_steps = None
+            self._replica_store(dev, self._plans)
         return self._plans
 
     @torch.no_grad()

@@ -368,6 +368,39 @@ class Conv3dPlan:
         return out
 
 
+class ReplicaPlanCache:
+    """Per-device plan cache for ``nn.DataParallel`` (SceneFlow/test_sceneflow_ddim.py:54-61, KITTI12/test.py): the
+    wrapper re-creates its replicas on EVERY forward, so a replica that folded BatchNorm / repacked weights for itself
+    would redo that work for every plan-holding module on every device and call.  Replicas keep a pointer to the module
+    they were copied from and park their plans there, keyed by device and valid for one weight version of the SOURCE
+    (the replicas' own weights are re-broadcast from it each time).  Mixed into the plan-holding modules."""
+
+    def _replica_source(self):
+        return self.__dict__.get("_plan_source")
+
+    def _mark_replica(self, replica):
+        replica.__dict__["_plan_source"] = self.__dict__.get("_plan_source") or self
+        return replica
+
+    def _source_version(self, src) -> int:
+        return sum(t._version for t in src.parameters()) + sum(t._version for t in src.buffers())
+
+    def _replica_lookup(self, device):
+        src = self._replica_source()
+        if src is None:
+            return None
+        hit = src.__dict__.setdefault("_replica_plans", {}).get(str(device))
+        return hit[1] if hit is not None and hit[0] == self._source_version(src) else None
+
+    def _replica_store(self, device, plans):
+        src = self._replica_source()
+        if src is not None:
+            src.__dict__.setdefault("_replica_plans", {})[str(device)] = (self._source_version(src), plans)
+
+    def _replica_clear(self):
+        self.__dict__.pop("_replica_plans", None)
+
+
 class Conv2dPlan:
     """Conv2d(k 3 or 1, stride 1, padding = dilation) [+ bias] [+ BatchNorm2d eval] [+ residual] [+ activation]
     [+ ConvGRU gate arithmetic] on the 2-D implicit-GEMM kernel: `convbn` / `BasicBlock` of the KITTI12 refinement

@@ -78,6 +78,28 @@ def test_data_parallel_replicas_build_their_own_plans(batch):
     assert out.device == torch.device(DEV)
 
 
+def test_data_parallel_replicas_reuse_the_plans_of_earlier_replicas(batch):
+    """nn.DataParallel re-creates its replicas on every forward: a replica must find the plans an earlier
+    replica of the same source built for this device instead of folding / packing all weights again -- and must NOT
+    find them once the source's weights changed."""
+    bare = _model(1)
+    first = _run(bare, batch)
+    r1 = bare._replicate_for_data_parallel()
+    assert r1._plans is None
+    p1 = r1.prepare()
+    r2 = bare._replicate_for_data_parallel()
+    assert r2._plans is None and r2.prepare() is p1                  # parked on the source, keyed by device
+    f1 = bare.feature_extraction._replicate_for_data_parallel()
+    q1 = f1.prepare()
+    assert bare.feature_extraction._replicate_for_data_parallel().prepare() is q1
+    sd2 = synth_state_dict(bare.state_dict(), seed=9, logit_gain=8.0)
+    bare.load_state_dict(sd2)                                        # new weights: every parked plan is stale
+    r3 = bare._replicate_for_data_parallel()
+    assert r3.prepare() is not p1
+    assert bare.feature_extraction._replicate_for_data_parallel().prepare() is not q1
+    assert not torch.equal(_run(bare, batch), first)
+
+
 def test_mis_sized_used_is_an_error_not_an_out_of_bounds_access(batch):
     model = _model(1)
     with torch.no_grad():

@@ -165,22 +165,37 @@ class IGEVDiffusionLoop:
         img = draw("x_T", tuple(asd.shape), torch.float32)
         mask = torch.zeros((b, h, w), dtype=torch.float32, device=dev)
         ens = used2 * self.ensemble_cof[0]
-        c0 = _dev_f32(coords0, "coords0").reshape(b, h, w)
         for i, (time, time_next) in enumerate(self._time_pairs()):
-            t = torch.full((b,), time, device=dev, dtype=torch.long)
-            n01, n01f = self._filter(img, t)
-            pred, coords1, net_list = self._gru_iterations(coords0, coords1, flow_init, iters, net_list, inp_list,
-                                                           corr_fn, n01f, stem_2x)
-            pred2 = _dev_f32(pred, "pred").reshape(b, 4 * h, 4 * w)
-            coef = self._coef(time, time_next, self.ensemble_cof[i + 1])
             eps = fill = None
             if time_next >= 0:
                 eps = draw("eps", tuple(img.shape), img.dtype)
                 fill = (self.sqrt_ac[time].item() * asd.double()
                         + self.sqrt_1mac[time].item() * draw("q", tuple(asd.shape), asd.dtype).double()).contiguous()
-            x_start, x_next, _ = self._update(pred2, used2, c0, n01, eps, fill, mask, ens, coef)
+            _, x_start, x_next, coords1, net_list = self.ddim_step(i, coords0, coords1, flow_init, iters, net_list, inp_list,
+                                                                   corr_fn, used2, img, mask, ens, eps, fill, stem_2x)
             img = x_start if time_next < 0 else x_next
         return ens
+
+    @torch.no_grad()
+    def ddim_step(self, i, coords0, coords1, flow_init, iters, net_list, inp_list, corr_fn, used, img, mask, ens=None,
+                  eps=None, fill=None, stem_2x=None):
+        """Iteration ``i`` of the loop of igev_stereo_ddim.py:306-351 from explicit state: ``img`` entering the step,
+        ``mask`` (updated in place), ``coords1`` and the hidden states ``net_list`` as the previous step left them,
+        ``eps`` = randn_like(img), ``fill`` = q_sample(asd, t).  Returns (pred [B,4h,4w], x_start fp32,
+        x_next fp64 | None, coords1, net_list)."""
+        time, time_next = self._time_pairs()[i]
+        b, _, h, w = img.shape
+        dev = img.device
+        t = torch.full((b,), time, device=dev, dtype=torch.long)
+        n01, n01f = self._filter(img, t)
+        pred, coords1, net_list = self._gru_iterations(coords0, coords1, flow_init, iters, net_list, inp_list,
+                                                       corr_fn, n01f, stem_2x)
+        pred2 = _dev_f32(pred, "pred").reshape(b, 4 * h, 4 * w)
+        used2 = _dev_f32(used, "used").reshape(b, 4 * h, 4 * w)
+        c0 = _dev_f32(coords0, "coords0").reshape(b, h, w)
+        coef = self._coef(time, time_next, self.ensemble_cof[i + 1])
+        x_start, x_next, _ = self._update(pred2, used2, c0, n01, eps, fill, mask, ens, coef)
+        return pred2, x_start, x_next, coords1, net_list
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -108,8 +108,9 @@ class IGEVLoopOracle:
         pn = (self.sr.gather(-1, t).reshape(bs) * n01 - x_start) / self.srm1.gather(-1, t).reshape(bs)
         return pn, x_start, pred, coords1
 
-    def ddim_sample(self, coords0, coords1, iters, used, asd, draw):
-        """:294-359."""
+    def ddim_sample(self, coords0, coords1, iters, used, asd, draw, trace=None):
+        """:294-359.  ``trace`` (a list) receives one dict per step: the state entering the step (img, mask_in,
+        coords1_in, nets_in), its outputs (disp, x_start, coords1_out, nets_out, mask_out, img_next) and the draws."""
         b, d, h, w = asd.shape
         img = draw("x_T", tuple(asd.shape), asd.dtype)
         final = [used]
@@ -117,11 +118,19 @@ class IGEVLoopOracle:
         times = list(reversed(torch.linspace(-1, 999, steps=self.S + 1).int().tolist()))
         for time, time_next in zip(times[:-1], times[1:]):
             t = torch.full((b,), time, dtype=torch.long)
+            rec = None
+            if trace is not None:
+                rec = {"time": time, "time_next": time_next, "img": img, "mask_in": mask, "coords1_in": coords1,
+                       "nets_in": list(self.net_list), "eps": None, "fill": None, "img_next": None}
+                trace.append(rec)
             pn, x_start, disp, coords1 = self.model_predictions(coords0, coords1, iters, img, t)
             dif = torch.abs(disp - used)
             keep = F.interpolate((dif < 5).float(), size=(h, w), mode="bilinear").squeeze(1)
             mask = torch.clamp(mask + keep, 0, 1)
             final.append(torch.where(dif < 3, disp, used))
+            if rec is not None:
+                rec.update(disp=disp, x_start=x_start, coords1_out=coords1, nets_out=list(self.net_list), mask_out=mask,
+                           out=final[-1])
             if time_next < 0:
                 img = x_start
                 continue
@@ -134,6 +143,8 @@ class IGEVLoopOracle:
             fill = (self.sqrt_ac.gather(-1, tt).reshape(1, 1, 1, 1) * asd
                     + self.sqrt_1m.gather(-1, tt).reshape(1, 1, 1, 1) * draw("q", tuple(asd.shape), asd.dtype))
             img = torch.where(mask.unsqueeze(1) == 0, fill, img)
+            if rec is not None:
+                rec.update(eps=eps, fill=fill, img_next=img)
         stack = torch.cat(final, dim=1)                                  # [B, S+1, H, W]
         return (stack * torch.tensor(self.cof).view(1, -1, 1, 1)).sum(dim=1)
 

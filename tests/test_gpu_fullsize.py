@@ -137,54 +137,131 @@ def test_hot_path_determinism_and_shard_invariance(hot):
         assert torch.equal(part, full[lo:hi]), (lo, hi)
 
 
-@pytest.mark.parametrize("pair", [0, 2])
-def test_fullsize_oracle_5step(pair):
-    """Pairs 0 and 2 of the bench workload (disparity ridge at 6 / 60 px; 960x512, 5 DDIM steps, injected noise) against oracle/acv_oracle.py, with the
-    contract's own numbers: per step |d disp| <= 1e-3 px on 99.9 % of the pixels and |EPE_hip - EPE_oracle| < 1e-4
-    against the synthetic ground truth.  Asserted (a) step by step from the oracle's state (teacher forced) and
-    (b) on HIP's own state with the oracle's renewal decisions imposed (decision forced); the free run is recorded
-    together with the number of renewal decisions that came out differently (oracle/loop_parity.py explains why
-    those are the only legitimate source of a larger difference)."""
+_ORACLE_RUNS = {}
+
+
+def _f64_state_dict(sd):
+    """Conv / attention weights in float64 (the time MLP stays fp32: its output is an input of the step)."""
+    return {k: (v.double() if v.is_floating_point() and not k.startswith("time_embedding") else v) for k, v in sd.items()}
+
+
+def oracle_run(pair, gain):
+    """The CPU oracle's 5-step run of one pair of the bench workload (960x512), cached for the tests of this module:
+    weights `synth_state_dict(seed=1, logit_gain=gain)`, inputs `synth_hot_inputs(seed=100)`, NoiseTape(1)."""
+    key = (pair, gain)
+    if key not in _ORACLE_RUNS:
+        from diffuvolume_amd.synth import synth_hot_inputs
+        from oracle import acv_oracle as O
+        from oracle import loop_parity as LP
+        sd = synth_state_dict(dv.ACVNet_DDIM(192, False, False).state_dict(), seed=1, logit_gain=gain)
+        model = dv.ACVNet_DDIM(192, False, False)
+        model.load_state_dict(sd, strict=True)
+        model = model.to(DEV).eval()
+        if pair == 0:
+            x = synth_hot_inputs(1, H, W, seed=100)
+        else:
+            x = {k: v[pair:pair + 1].clone() for k, v in synth_hot_inputs(3, H, W, seed=100).items()}
+        orc = O.ACVDiffusionOracle(sd)
+        vol = O.attention_concat_volume(x["att"], O.build_concat_volume(x["cl"], x["cr"], D))
+        x_T = orc.encode_x_T(x["dq"])
+        vol_d = dv.build_concat_attention_volume(x["cl"].to(DEV), x["cr"].to(DEV), x["att"].to(DEV), D)
+        assert rel(vol_d.cpu(), vol) < 1e-6
+        assert torch.equal(model.encode_disparity(x["dq"].to(DEV)).cpu(), x_T)
+        final_o, stack_o, trace = LP.oracle_trajectory(orc, vol, x["used"], x_T, seed=1)
+        _ORACLE_RUNS.clear()                                  # one run resident at a time (a trace holds ~0.5 GB)
+        _ORACLE_RUNS[key] = dict(sd=sd, model=model, x=x, orc=orc, vol=vol, x_T=x_T, vol_d=vol_d, used_d=x["used"].to(DEV),
+                                 final_o=final_o, stack_o=stack_o, trace=trace)
+    return _ORACLE_RUNS[key]
+
+
+def _dump(name, report):
     import json
     import os
-    from diffuvolume_amd.synth import synth_hot_inputs
-    from oracle import acv_oracle as O
-    from oracle import loop_parity as LP
-    sd = synth_state_dict(dv.ACVNet_DDIM(192, False, False).state_dict(), seed=1, logit_gain=8.0)
-    model = dv.ACVNet_DDIM(192, False, False)
-    model.load_state_dict(sd, strict=True)
-    model = model.to(DEV).eval()
-    if pair == 0:
-        x = synth_hot_inputs(1, H, W, seed=100)
-    else:
-        x = {k: v[pair:pair + 1].clone() for k, v in synth_hot_inputs(3, H, W, seed=100).items()}
-    orc = O.ACVDiffusionOracle(sd)
-    vol = O.attention_concat_volume(x["att"], O.build_concat_volume(x["cl"], x["cr"], D))
-    x_T = orc.encode_x_T(x["dq"])
-    vol_d = dv.build_concat_attention_volume(x["cl"].to(DEV), x["cr"].to(DEV), x["att"].to(DEV), D)
-    assert rel(vol_d.cpu(), vol) < 1e-6
-    assert torch.equal(model.encode_disparity(x["dq"].to(DEV)).cpu(), x_T)
-    used_d = x["used"].to(DEV)
-    final_o, stack_o, trace = LP.oracle_trajectory(orc, vol, x["used"], x_T, seed=1)
-    tf = LP.teacher_forced(model, trace, vol_d, used_d, x["used"], x["gt"])
-    df = LP.decision_forced(model, trace, vol_d, used_d, x_T, x["gt"])
-    fr = LP.free_run(model, trace, stack_o, final_o, vol_d, used_d, x_T, x["gt"], seed=1)
-    report = {"teacher_forced": tf, "decision_forced": df, "free_run": fr}
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(f"gpurun_out/parity_fullsize_5step_pair{pair}.json", "w") as f:
+    with open(f"gpurun_out/{name}.json", "w") as f:
         json.dump(report, f, indent=1)
     print(json.dumps(report))
+
+
+@pytest.mark.parametrize("pair", [0, 2])
+def test_fullsize_oracle_5step(pair):
+    """Pairs 0 and 2 of the bench workload (disparity ridge at 6 / 60 px; 960x512, 5 DDIM steps, injected noise) against
+    oracle/acv_oracle.py with the contract's own numbers: per step |EPE_hip - EPE_oracle| < 1e-4 and |d disp| <= 1e-3 px
+    on 99.9 % of the pixels.  With these untrained weights (mean uncertainty 30-50 px) two fp32 evaluations of the
+    network differ by more than that on ~0.1-0.15 % of ALL pixels, so the pixel bar is asserted
+    RAW where the reference itself is confident (`frac_gt_1e-3_where_unc_lt_3`, its own `unc < 3` criterion), with a
+    ceiling of 2e-3 on the raw share over all pixels, and raw on the model's output (the ensemble).  The spread-scaled
+    `frac_gt_bar` is kept as a diagnostic only.  Teacher forced, decision forced and free run (oracle/loop_parity.py)."""
+    from oracle import loop_parity as LP
+    r = oracle_run(pair, 8.0)
+    model, x, trace = r["model"], r["x"], r["trace"]
+    tf = LP.teacher_forced(model, trace, r["vol_d"], r["used_d"], x["used"], x["gt"])
+    df = LP.decision_forced(model, trace, r["vol_d"], r["used_d"], r["x_T"], x["gt"])
+    fr = LP.free_run(model, trace, r["stack_o"], r["final_o"], r["vol_d"], r["used_d"], r["x_T"], x["gt"], seed=1)
+    _dump(f"parity_fullsize_5step_pair{pair}", {"teacher_forced": tf, "decision_forced": df, "free_run": fr})
     for s in tf:
-        assert s["frac_gt_bar"] <= LP.BAR_FRAC, ("teacher forced", s)
         assert s["epe_delta"] < LP.BAR_EPE, ("teacher forced", s)
+        assert s["frac_gt_1e-3_where_unc_lt_3"] <= LP.BAR_FRAC, ("teacher forced, confident pixels, raw bar", s)
+        assert s["frac_gt_1e-3"] <= 2e-3, ("teacher forced, all pixels, raw ceiling", s)
+        assert s["frac_gt_bar"] <= LP.BAR_FRAC, ("teacher forced", s)
         assert s["mask_max_abs"] <= 1.0
         if "x_next_max_abs_where_decisions_agree" in s:
             assert s["x_next_mean_abs_where_decisions_agree"] < 1e-4, s
     flips = sum(s["flips_mask_zero"] for s in fr["steps"])
     for s in df + (fr["steps"] if flips == 0 else []):
-        # trajectory level (HIP on its own state): the contract's EPE bar at every step; pixels held to the same
-        # spread-scaled bar -- at this size the step map does not amplify the 1e-4 px state differences beyond it
+        # trajectory level (HIP on its own state): the contract's EPE bar at every step, the raw pixel bar on the
+        # confident pixels -- at this size the step map does not amplify the 1e-4 px state differences beyond it
         assert s["epe_delta"] < LP.BAR_EPE, s
-        assert s["frac_gt_bar"] <= LP.BAR_FRAC, s
+        assert s["frac_gt_1e-3_where_unc_lt_3"] <= LP.BAR_FRAC and s["frac_gt_1e-3"] <= 3e-3, s
     assert fr["final"]["epe_delta"] < LP.BAR_EPE, fr["final"]
     assert fr["final"]["frac_gt_1e-3"] <= LP.BAR_FRAC or flips > 0, fr["final"]   # the ensemble output: raw contract bar
+
+
+def test_fullsize_fp64_triangulation():
+    """Pair 0 at 960x512, every DDIM step from the fp32 oracle's state: the HIP path and the fp32 oracle against the
+    oracle evaluated in float64 (weights and activations).  Asserted RAW, no scaling: the HIP disparity is within
+    1e-3 px of the float64 value on 99.9 % of ALL pixels at every step, and no further from it than 1.5x the fp32
+    reference path itself -- the distance between the two fp32 paths (test above) is the sum of these two."""
+    from oracle import acv_oracle as O
+    from oracle import loop_parity as LP
+    r = oracle_run(0, 8.0)
+    sd64 = _f64_state_dict(r["sd"])
+    tri = LP.teacher_forced_vs_fp64(r["model"], r["orc"], O.ACVDiffusionOracle(sd64), r["trace"], r["vol"], r["vol_d"],
+                                    r["used_d"])
+    _dump("parity_fullsize_fp64_triangulation", tri)
+    for s in tri:
+        h, o = s["hip_vs_fp64"], s["oracle32_vs_fp64"]
+        assert h["frac_gt_1e-3"] <= LP.BAR_FRAC, ("HIP vs float64, raw bar, all pixels", s)
+        assert h["mean_abs_px"] <= 1.5 * o["mean_abs_px"] + 2e-5, s
+        assert h["frac_gt_1e-3"] <= 2.0 * o["frac_gt_1e-3"] + 2e-4, s
+
+
+def test_fullsize_oracle_5step_conditioned():
+    """The same comparison on a CONDITIONED network: logit gain 32 instead of 8 on the classifier
+    head, which makes the reference confident (uncertainty < 3 px, its own renewal criterion) on more than half of
+    the pixels from step 2 on -- a gain sweep on the CPU oracle gave 5 % / 60 % / 78 % / 89 % confident pixels for
+    gains 8 / 32 / 64 / 128, with |cost| growing in proportion (mean 30 at gain 32).  On those pixels the contract's
+    1e-3 px bar is asserted RAW at every teacher-forced step, beside |d EPE| < 1e-4.  What a gain cannot do is make
+    the remaining pixels unimodal: there the soft-argmax of this untrained network sits between several modes of
+    similar weight, and ANY two fp32 evaluations differ (the fp32 oracle against its own float64 evaluation exceeds
+    1e-3 px on 2.6 % of all pixels at this gain, measured on the CPU); the raw share over all pixels is recorded in the
+    report, with that float64 triangulation beside it for the first two steps, and held to that order of magnitude."""
+    from oracle import acv_oracle as O
+    from oracle import loop_parity as LP
+    r = oracle_run(0, 32.0)
+    model, x, trace = r["model"], r["x"], r["trace"]
+    tf = LP.teacher_forced(model, trace, r["vol_d"], r["used_d"], x["used"], x["gt"])
+    fr = LP.free_run(model, trace, r["stack_o"], r["final_o"], r["vol_d"], r["used_d"], r["x_T"], x["gt"], seed=1)
+    sd64 = _f64_state_dict(r["sd"])
+    tri = LP.teacher_forced_vs_fp64(model, r["orc"], O.ACVDiffusionOracle(sd64), trace[:2], r["vol"], r["vol_d"], r["used_d"])
+    _dump("parity_fullsize_5step_conditioned", {"logit_gain": 32.0, "teacher_forced": tf, "free_run": fr,
+                                                "fp64_triangulation_steps_1_2": tri})
+    for s in tf:
+        assert s["epe_delta"] < LP.BAR_EPE, s
+        assert s["frac_gt_1e-3_where_unc_lt_3"] <= LP.BAR_FRAC, ("confident pixels, raw bar", s)
+        if s["step"] >= 2:
+            assert s["share_unc_lt_3"] >= 0.5, s
+    for s in tri:          # all pixels, raw: HIP is no further from the float64 value than the fp32 reference path is
+        assert s["hip_vs_fp64"]["frac_gt_1e-3"] <= 1.5 * s["oracle32_vs_fp64"]["frac_gt_1e-3"] + 1e-3, s
+        assert s["hip_vs_fp64"]["frac_gt_1e-3_where_unc_lt_3"] <= LP.BAR_FRAC, s
+    assert fr["final"]["epe_delta"] < LP.BAR_EPE, fr["final"]

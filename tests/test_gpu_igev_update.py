@@ -121,6 +121,75 @@ def test_ddim_loop_with_the_real_update_block():
     assert float(d.median()) < 2e-3 and float(d.mean()) < 5e-2, (float(d.median()), float(d.mean()))
 
 
+def test_ddim_loop_20_steps_teacher_forced_vs_oracle():
+    """BASELINE config 5 runs 20 DDIM steps (the reference hard-codes 2, igev_stereo_ddim.py:124): the IGEV loop with
+    the REAL update block (HIP 2-D convolutions with fused gates) and the HIP filtered lookup over all 20 steps against
+    oracle/igev_oracle.py driven by the oracle's own update block -- every step teacher forced (HIP from the oracle's
+    img / mask / coords1 / hidden states entering that step, igev_stereo_ddim.py:306-351), at the contract's raw bars:
+    |d disp| <= 1e-3 px on 99.9 % of the pixels and |EPE_hip - EPE_oracle| < 1e-4 (against `used`), then the free run's
+    ensemble output."""
+    from diffuvolume_amd.geometry_ddim import Combined_Geo_Encoding_Volume
+    from diffuvolume_amd.igev_stereo_ddim import DynamicHead180, IGEVDiffusionLoop
+    from diffuvolume_amd.synth import NoiseTape, synth_state_dict, toy_upsample_disp
+    from diffuvolume_amd.update import BasicMultiUpdateBlock
+    b, h, w, steps, iters = 1, 16, 24, 20, 4
+    cof = (0.6,) + (0.0,) * (steps - 2) + (0.1, 0.3)
+    sd = update_state_dict(141)
+    sd["disp_head.conv2.weight"] = sd["disp_head.conv2.weight"] * 0.05      # keep the per-iteration step ~1 bin
+    m = BasicMultiUpdateBlock(ARGS, hidden_dims=[128, 128, 128])
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    head = DynamicHead180()
+    head.load_state_dict(synth_state_dict(head.state_dict(), seed=142), strict=True)
+    head = head.eval()
+    net, inp, _, _ = update_inputs(143, b, h, w)
+    geo = torch.randn(b, 8, 48, h, w, generator=_gen(144, "geo"))
+    f1, f2 = torch.randn(b, 16, h, w, generator=_gen(144, "f1")), torch.randn(b, 16, h, w, generator=_gen(144, "f2"))
+    init = torch.rand(b, 1, h, w, generator=_gen(144, "init")) * 40
+    used = torch.nn.functional.interpolate(init * 4, scale_factor=4, mode="bilinear") + 1.5
+    asd = torch.rand(b, 48, h, w, generator=_gen(144, "asd")) * 2 - 1
+    orc = I.IGEVLoopOracle(head.state_dict(), lambda n, i, c, f, **kw: I.update_block(sd, n, i, c, f), toy_upsample_disp,
+                           geo, f1, f2, sampling_timesteps=steps, cof=cof, net_list=net, inp_list=inp)
+    trace = []
+    final_ref = orc.ddim_sample(init, init, iters, used, asd, NoiseTape(145), trace=trace)
+    assert len(trace) == steps and [r["time"] for r in trace][:3] == [999, 949, 899] and trace[-1]["time_next"] == -1
+
+    geo_fn = Combined_Geo_Encoding_Volume(dev(f1), dev(f2), dev(geo), radius=4, num_levels=2)
+    loop = IGEVDiffusionLoop(head.to(DEV), m, toy_upsample_disp, n_gru_layers=3, slow_fast_gru=False,
+                             sampling_timesteps=steps, ensemble_cof=cof)
+    dinp = [[dev(x) for x in l] for l in inp]
+    u2 = used.reshape(b, 4 * h, 4 * w)
+    worst = {"frac": 0.0, "epe": 0.0, "max": 0.0}
+    for i, r in enumerate(trace):
+        mask = dev(r["mask_in"]).clone()
+        eps = None if r["eps"] is None else dev(r["eps"])
+        fill = None if r["fill"] is None else dev(r["fill"]).double().contiguous()
+        pred, xs, xn, c1, nets = loop.ddim_step(i, dev(init), dev(r["coords1_in"]), None, iters,
+                                                [dev(t) for t in r["nets_in"]], dinp, geo_fn, dev(used), dev(r["img"]),
+                                                mask, None, eps, fill, None)
+        d = (pred.cpu() - r["disp"].reshape(b, 4 * h, 4 * w)).abs()
+        frac = float((d > 1e-3).float().mean())
+        epe = abs(float((pred.cpu() - u2).abs().mean()) - float((r["disp"].reshape(b, 4 * h, 4 * w) - u2).abs().mean()))
+        worst = {"frac": max(worst["frac"], frac), "epe": max(worst["epe"], epe), "max": max(worst["max"], float(d.max()))}
+        assert frac <= 1e-3 and epe < 1e-4, (i + 1, frac, epe, float(d.max()))
+        torch.testing.assert_close(c1.cpu(), r["coords1_out"], atol=1e-3, rtol=1e-5)
+        for a_, b_ in zip(nets, r["nets_out"]):
+            assert rel_err(a_, b_) < 1e-4
+        assert float((mask.cpu() - r["mask_out"]).abs().max()) <= 1.0
+        same = ((xs.cpu() - r["x_start"]).abs() < 1e-2).all(dim=1)
+        assert float(same.float().mean()) > 0.99
+        if xn is not None:
+            agree = ((mask.cpu() == 0) == (r["mask_out"] == 0)) & same
+            dx = (xn.cpu() - r["img_next"]).abs()[agree.unsqueeze(1).expand_as(r["img_next"])]
+            assert float(dx.mean()) < 1e-4
+    print("igev 20-step teacher forced, worst over steps:", worst)
+    final = loop.ddim_sample(dev(init), dev(init), None, iters, [dev(x) for x in net], dinp, geo_fn, dev(used), dev(asd),
+                             None, noise=NoiseTape(145))
+    d = (final.cpu() - final_ref).abs()
+    assert abs(float((final.cpu() - u2).abs().mean()) - float((final_ref - u2).abs().mean())) < 1e-3
+    assert float(d.median()) < 2e-3, (float(d.median()), float(d.mean()))
+
+
 @pytest.mark.parametrize("shape", [(2, 5, 24, 78), (1, 3, 7, 9), (1, 2, 1, 5), (2, 4, 12, 39)])
 def test_update_glue_kernels_vs_torch(shape):
     """csrc/update_glue.hip: `pool2x`, `interp` (bilinear, align_corners=True) and the single-input-channel 7x7 `convd1`

@@ -168,13 +168,17 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
   // row (slot s of row n holds quad s ^ (n>>2)): the B-fragment ds_read_b128 of 16 rows then covers 16 distinct
   // slots of the 256-byte bank row without padding ----
   const int dma_lo = (lane >> 2) * 16 + (((lane & 3) ^ ((lane >> 4) & 3)) * 4);
+  const int dma_voff = dma_lo * 4;                 // the lane part of a piece's source address: constant
   auto dma_u = [&](int c0, float* ub) __attribute__((always_inline)) {
-    const float* src = a.wpk + ((size_t)(c0 >> 2) * a.nco + tc) * U_CHUNK + dma_lo;
+    // piece base on the scalar unit (SGPR pair), lane offset in one loop-invariant VGPR: a 64-bit vector add per piece
+    // (v_lshl_add_u64) is an isolated vector-ALU instruction in the MFMA stream -- the matrix pipe drains for it
+    // (~60 cycles each, tools/probes/mfma_f32_neighbours.hip)
+    const float* src = a.wpk + ((size_t)(c0 >> 2) * a.nco + tc) * U_CHUNK;
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
       const int piece = wave + 4 * q;
 #ifdef DV_WINO_BUILTIN_DMA
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 256),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + dma_lo + piece * 256),
                                        (__attribute__((address_space(3))) void*)(ub + piece * 256), 16, 0, 0);
 #else
       // Issued as inline asm rather than through the builtin: the compiler treats an LDS-DMA as an LDS store that any
@@ -183,12 +187,14 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
       // the manual s_waitcnt vmcnt + barrier at the top of the next chunk; not counting it makes the compiler's own
       // vmcnt waits for the raw registers stricter, never looser (vector memory operations complete in order).
       const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(ub + piece * 256);
-      const float* gp = src + piece * 256;
+      const uint64_t gb = reinterpret_cast<uint64_t>(src + piece * 256);
+      const uint64_t gbs = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)gb) |
+                           ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(gb >> 32)) << 32);
       unsigned m0_saved;       // M0 is reserved by the compiler: hand it back as found
       // (s_nop 0: gfx9 needs one wait state between a scalar write of M0 and the LDS-DMA that reads it; the hazard
       // recogniser does not look inside inline asm -- tests/test_isa_lint.py checks the compiled stream)
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(m0_saved) : "s"(lds_addr), "v"(gp) : "memory");
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                   : "=&s"(m0_saved) : "s"(lds_addr), "v"(dma_voff), "s"(gbs) : "memory");
 #endif
     }
   };

@@ -30,6 +30,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // SHAPE = how the 16 Winograd tiles of a plane's M index lie in the plane (as in conv3d_wino.hip): 0 -> 2 tile rows x
 // 8 tile columns (4 x 16 outputs), 1 -> 4 x 4 (8 x 8 outputs), 2 -> 8 x 2 (16 x 4 outputs).
@@ -57,6 +58,18 @@ constexpr int U_CHUNK = 3 * 2 * 4 * 16 * 16;   // packed weight floats per (chun
 constexpr int V_PLANE = 4 * 16 * 16;           // [kq 4][tile 16][position 16]
 constexpr int V_BUF = 6 * V_PLANE;             // 6 transformed planes of a chunk, 24 KB
 }  // namespace pg
+
+#ifdef DV_PS_STAMPS
+// diagnostic build only (tools/wino_ps_bench.cpp -DDV_PS_STAMPS): s_memtime stamps of block 0, consumer wave 0 and
+// producer wave 4, first 48 items; written to a buffer nothing else reads
+__device__ unsigned long long g_ps_stamps[2][48][8];
+#define PS_STAMP(who, item, slot)                                                              \
+  do {                                                                                         \
+    if (blockIdx.x == 0 && (item) < 48 && lane == 0) g_ps_stamps[who][item][slot] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define PS_STAMP(who, item, slot) do {} while (0)
+#endif
 
 struct WinoPsArgs {
   const float* in;
@@ -129,6 +142,18 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino_ps_kernel(WinoPsArgs a) {
     // lane (tile j, channel kq) of wave w: A quad of transform positions 4*p4 .. 4*p4+3 of plane w + kd = one
     // ds_read_b128 of V row (kq, j); B quad = the same row of U for cout j.  Slot s of a row holds quad s ^ (j >> 2):
     // the 16 lanes of a ds_read_b128 lane group then cover 16 distinct 16-byte slots of the 256-byte bank row.
+#ifdef DV_PS_CONS_PRIO
+    __builtin_amdgcn_s_setprio(DV_PS_CONS_PRIO);
+#endif
+    // Between two MFMAs of a stream the matrix pipe accepts another vector-ALU instruction only after it has drained:
+    // an isolated v_or / v_add costs ~60 cycles (tools/probes/mfma_f32_neighbours.hip), so the chunk body contains
+    // none -- every LDS address is a loop-invariant register plus an immediate, with the buffer index a template
+    // parameter.
+    // lane (tile j, channel kq) of wave w: A quad of transform positions 4*p4 .. 4*p4+3 of plane w + kd = one
+    // ds_read_b128 of V row (kq, j); B quad = the same row of U for cout j.  The buffer flip of the eight address
+    // registers is left to the compiler: it clusters the eight vector ops with the first MFMAs of a chunk and hoists
+    // the block barrier over the last ~20 MFMAs of the previous one, so that the first LDS reads of a chunk are in
+    // flight behind them (pinning the flip behind the barrier by inline asm lost that: consumer-only 2.74 vs 2.20 ms).
     int ab_lo[4];
 #pragma unroll
     for (int p4 = 0; p4 < 4; ++p4) ab_lo[p4] = 4 * ((kq * 16 + j) * 16 + ((p4 ^ ((j >> 2) & 3)) * 4));
@@ -165,6 +190,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino_ps_kernel(WinoPsArgs a) {
           }
       }
     };
+    auto compute_item = [&](int m, auto first_tag) __attribute__((always_inline)) { compute(m & 1, first_tag); };
 
     // epilogue of one tile: Y = At M A per 2x2-tile group, BN scale / bias, residual, activation, 16-byte stores.
     // Accumulator rows 4kq..4kq+3 = the 2x2 tiles of group kq = a 4 x 4 output patch at (4*(kq/GC), 4*(kq%GC)).
@@ -216,7 +242,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino_ps_kernel(WinoPsArgs a) {
               if (a.residual) v += rv[yr];
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = mish ? dv_act(v[e], DV_ACT_MISH) : fmaxf(v[e], v[e] * slope);
+#ifdef DV_PS_ABLATE_STORES
+              asm volatile("" ::"v"(v));
+#else
               *reinterpret_cast<f32x4*>(a.out + o) = v;
+#endif
             } else if (t.y0 + yq + yr < a.H) {
 #pragma unroll
               for (int e = 0; e < 4; ++e)
@@ -235,25 +265,76 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino_ps_kernel(WinoPsArgs a) {
     int m = 0;
 #pragma unroll 1
     for (int k = 0; k < nt_mine; ++k) {
-      compute(m & 1, std::true_type{});
+      if (wave == 0) PS_STAMP(0, m, 0);
+#ifndef DV_PS_ABLATE_CONSUMER
+      compute_item(m, std::true_type{});
+#endif
+      if (wave == 0) PS_STAMP(0, m, 1);
       __syncthreads();                             // done with buffers m & 1; item m + 1 is ready
+      if (wave == 0) PS_STAMP(0, m, 2);
       ++m;
 #pragma unroll 1
       for (int c = 1; c < nchunk; ++c) {
-        compute(m & 1, std::false_type{});
+        if (wave == 0) PS_STAMP(0, m, 0);
+#ifndef DV_PS_ABLATE_CONSUMER
+        compute_item(m, std::false_type{});
+#endif
+        if (wave == 0) PS_STAMP(0, m, 1);
         __syncthreads();
+        if (wave == 0) PS_STAMP(0, m, 2);
         ++m;
       }
+#if !defined(DV_PS_ABLATE_CONSUMER) && !defined(DV_PS_ABLATE_EPILOGUE)
       epilogue(tile_of(k));                        // (the producers are already preparing the item after next)
+#elif defined(DV_PS_ABLATE_EPILOGUE)
+      if (a.act == 12345) epilogue(tile_of(k));    // timing-only build: keeps the accumulators alive, never runs
+#endif
+      if (wave == 0) PS_STAMP(0, m - 1, 3);
+#ifdef DV_PS_STAMPS
+      if (wave == 0 && blockIdx.x == 0 && lane == 0) { g_ps_stamps[0][47][7] = __builtin_amdgcn_s_memtime(); g_ps_stamps[0][47][6] = (unsigned long long)m; }
+      if (wave == 0 && blockIdx.x == 0 && lane == 0 && k == 0) g_ps_stamps[0][47][5] = __builtin_amdgcn_s_memrealtime();
+      if (wave == 0 && blockIdx.x == 0 && lane == 0) g_ps_stamps[0][47][4] = __builtin_amdgcn_s_memrealtime();
+#endif
     }
     return;
   }
 
   // ============================================= producers =============================================
+#ifdef DV_PS_PROD_PRIO
+  __builtin_amdgcn_s_setprio(DV_PS_PROD_PRIO);
+#endif
   const int p = wave - 4;                          // this wave's channel of every chunk; V / U rows kq = p
+  const int vol_bytes = __builtin_amdgcn_readfirstlane((int)(vol * sizeof(float)));   // < 2^31 (checked by the host)
+  const int pl = kq;
+  const int p_tr = 2 * ((j >> 2) / GC) + (j & 1), p_tc = 2 * ((j >> 2) % GC) + ((j >> 1) & 1);
+  const int patch_lo = pl * PZ + (2 * p_tr) * RX + 2 * p_tc;
+  const int patch2_lo = lane < 32 ? patch_lo + 4 * PZ : patch_lo;          // lanes 32..63: any valid address
+  const int v_row = (p * 16 + j) * 16;
+  const int swz = (j >> 2) & 3;
+  const int dma_lo = (lane >> 2) * 16 + (((lane & 3) ^ ((lane >> 4) & 3)) * 4);
   float* const rawp = raw_s + p * RAWC;            // wave-private raw brick [z][y][RX], plane stride PZ
-  // staging plan: NSP positions of the haloed brick per lane; LDS side fixed, global side per tile
+
+  struct Item {
+    int k, c0;           // tile ordinal, first channel of the chunk
+    TileXY t;
+  };
+  auto next_item = [&](Item& it) __attribute__((always_inline)) {      // -> true when the tile changed
+    it.c0 += KC;
+    if (it.c0 < a.Cin) return false;
+    it.c0 = 0;
+    ++it.k;
+    if (it.k < nt_mine) it.t = tile_of(it.k);
+    return true;
+  };
+
+  // ---- raw brick: NSP dword positions per lane (buffer loads: zero padding and the channel tail from the range check,
+  // offset 2^31 / zero records), the filter value multiplied in, dword LDS stores into the wave-private padded brick.
+  // Two register sets: a brick is fetched TWO slots (~3.5 us) before it is committed -- one slot is less than a loaded
+  // HBM round trip, and then this wave reaches the barrier late and all eight wait.
   int lro[NSP];
+  unsigned sob[NSP];
+  float scl_plan[HAS_SCALE ? NSP : 1];
+  float vin[2][NSP], scl[2][HAS_SCALE ? NSP : 1];
 #pragma unroll
   for (int i = 0; i < NSP; ++i) {
     const int r = lane + 64 * i;
@@ -261,23 +342,6 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino_ps_kernel(WinoPsArgs a) {
     const int yy = r2 / IX, xx = r2 - yy * IX;
     lro[i] = r < PRAW ? zz * PZ + yy * RX + xx : G::DUMP;
   }
-  unsigned sob[NSP];                               // byte offset in a channel volume, 2^31 outside the volume
-  float scl[HAS_SCALE ? NSP : 1];
-  float vin[NSP];
-  const int vol_bytes = __builtin_amdgcn_readfirstlane((int)(vol * sizeof(float)));   // < 2^31 (checked by the host)
-
-  // patches of this lane: tile j of plane pl (round 0) and of plane 4 + pl (round 1, lanes 0..31)
-  const int pl = kq;
-  const int p_tr = 2 * ((j >> 2) / GC) + (j & 1), p_tc = 2 * ((j >> 2) % GC) + ((j >> 1) & 1);
-  const int patch_lo = pl * PZ + (2 * p_tr) * RX + 2 * p_tc;
-  const int v_row = (p * 16 + j) * 16;
-  const int swz = (j >> 2) & 3;
-  const int dma_lo = (lane >> 2) * 16 + (((lane & 3) ^ ((lane >> 4) & 3)) * 4);
-
-  struct Item {
-    int k, c0;           // tile ordinal, first channel of the chunk
-    TileXY t;
-  };
   auto plan_tile = [&](const TileXY& t) __attribute__((always_inline)) {
     const float* scb = (HAS_SCALE && a.in_scale) ? a.in_scale + (size_t)t.b * vol : nullptr;
 #pragma unroll
@@ -290,108 +354,234 @@ __global__ __launch_bounds__(512, 1) void conv3d_wino_ps_kernel(WinoPsArgs a) {
                       (unsigned)x < (unsigned)a.W;
       const unsigned sp = ok ? (unsigned)((z * a.H + y) * a.W + x) : 0u;
       sob[i] = ok ? sp * 4u : 0x80000000u;
-      if (HAS_SCALE) scl[i] = (ok && scb) ? scb[sp] : 1.f;
+      if (HAS_SCALE) scl_plan[i] = (ok && scb) ? scb[sp] : 1.f;
     }
   };
-  auto fetch = [&](const Item& it) __attribute__((always_inline)) {
+  // The loads of this pipeline are issued as inline asm and waited for by hand: a register set is consumed two slots
+  // (two loop iterations) after its loads were issued, with the loads of the later items still in flight behind them,
+  // and the compiler's wait-count insertion answers a load carried around a loop back-edge with s_waitcnt vmcnt(0)
+  // -- which cuts the prefetch distance back to one slot.  vmcnt counts in issue order, so "all but the N youngest"
+  // with N = the loads issued after the set's own is exact (VM_AFTER_*).
+  auto fetch = [&](const Item& it, auto set_tag) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_tag)::value;
     const int c = it.c0 + p;
-    const float* base = a.in + ((size_t)it.t.b * a.Cin + (c < a.Cin ? c : 0)) * vol;
-    const uint64_t fb = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)reinterpret_cast<uint64_t>(base)) |
-                        ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(reinterpret_cast<uint64_t>(base) >> 32)) << 32);
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(fb), 0, c < a.Cin ? vol_bytes : 0, 0x00020000);
+    const uint64_t base = reinterpret_cast<uint64_t>(a.in + ((size_t)it.t.b * a.Cin + (c < a.Cin ? c : 0)) * vol);
+    i32x4 desc;                                     // raw buffer, stride 0; zero records for the channel tail
+    desc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
+    desc[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(base >> 32) & 0xffffu));
+    desc[2] = c < a.Cin ? vol_bytes : 0;
+    desc[3] = 0x00020000;
 #pragma unroll
-    for (int i = 0; i < NSP; ++i) vin[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)sob[i], 0, 0));
+    for (int i = 0; i < NSP; ++i) {
+      float v;
+      asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(v) : "v"(sob[i]), "s"(desc) : "memory");
+      vin[SET][i] = v;
+      if (HAS_SCALE) scl[SET][i] = scl_plan[i];
+    }
   };
-  auto commit = [&]() __attribute__((always_inline)) {
+  auto scale_vin = [&](auto set_tag) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_tag)::value;
+    if (HAS_SCALE) {
 #pragma unroll
-    for (int i = 0; i < NSP; ++i) rawp[lro[i]] = HAS_SCALE ? vin[i] * scl[i] : vin[i];
+      for (int i = 0; i < NSP; ++i) vin[SET][i] *= scl[SET][i];
+    }
   };
-  auto dma_u = [&](const Item& it, int buf) __attribute__((always_inline)) {
-    const float* src = a.wpk + ((size_t)(it.c0 >> 2) * a.nco + it.t.tc) * U_CHUNK + dma_lo;
-    float* ub = u_s + buf * U_CHUNK;
+  auto commit_raw = [&](auto set_tag) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_tag)::value;
+#pragma unroll
+    for (int i = 0; i < NSP; ++i) rawp[lro[i]] = vin[SET][i];
+  };
+  // weights of a chunk: the packed image is the LDS image; each producer wave moves six 1-KB pieces (16 cout rows x 4
+  // position quads) through registers -- six independent 16-byte buffer loads (descriptor and piece offset on the
+  // scalar unit, one constant lane offset), six 16-byte LDS stores two slots later.  Slot s of a row holds quad
+  // s ^ (row >> 2): conflict-free B-fragment reads without padding.
+  f32x4 uq[2][6];
+  i32x4 u_desc;
+  {
+    const uint64_t wb = reinterpret_cast<uint64_t>(a.wpk);
+    u_desc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)wb);
+    u_desc[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(wb >> 32) & 0xffffu));
+    u_desc[2] = (int)((size_t)nchunk * a.nco * U_CHUNK * 4);
+    u_desc[3] = 0x00020000;
+  }
+  const int u_voff = dma_lo * 4;
+  auto load_u = [&](const Item& it, auto set_tag) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_tag)::value;
+    const int so = ((it.c0 >> 2) * a.nco + it.t.tc) * (U_CHUNK * 4) + p * 1024;
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
-      const int piece = p + 4 * q;
-      // inline asm: the compiler would answer an LDS-DMA builtin with s_waitcnt vmcnt(0) before the next LDS store
-      // (conv3d_wino.hip); completion is covered by the manual s_waitcnt before the block barrier.  M0 is reserved
-      // by the compiler: handed back as found; one wait state between the scalar write of M0 and the DMA.
-      const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(ub + piece * 256);
-      const float* gp = src + piece * 256;
-      unsigned m0_saved;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(m0_saved) : "s"(lds_addr), "v"(gp) : "memory");
+      f32x4 v;
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(u_voff), "s"(u_desc), "s"(so + q * 4096) : "memory");
+      uq[SET][q] = v;
     }
   };
-  // V = Bt d B of one 4x4 patch on packed-fp32 adds (the transform of conv3d_wino.hip) and its 16 values as four
-  // 16-byte stores into V row (p, j) of plane P
-  auto transform_plane = [&](int P, int buf) __attribute__((always_inline)) {
-    const float* src = rawp + patch_lo + (P - pl) * PZ;
-    f32x2 d[4][2];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      d[r][0] = *reinterpret_cast<const f32x2*>(src + r * RX);
-      d[r][1] = *reinterpret_cast<const f32x2*>(src + r * RX + 2);
-    }
-    float* dst = v_s + buf * V_BUF + P * V_PLANE + v_row;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      f32x2 t0, t1, o0, o1;
-      const int ra = r == 0 ? 0 : (r == 2 ? 2 : 1), rb2 = r == 0 ? 2 : (r == 1 ? 2 : (r == 2 ? 1 : 3));
-      if (r == 1) {
-        asm("v_pk_add_f32 %0, %1, %2" : "=v"(t0) : "v"(d[ra][0]), "v"(d[rb2][0]));
-        asm("v_pk_add_f32 %0, %1, %2" : "=v"(t1) : "v"(d[ra][1]), "v"(d[rb2][1]));
-      } else {
-        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t0) : "v"(d[ra][0]), "v"(d[rb2][0]));
-        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t1) : "v"(d[ra][1]), "v"(d[rb2][1]));
-      }
-      asm("v_pk_add_f32 %0, %2, %3 op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
-          "v_pk_add_f32 %1, %3, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]"
-          : "=&v"(o0), "=&v"(o1) : "v"(t0), "v"(t1));
-      *reinterpret_cast<f32x4*>(dst + ((r ^ swz) * 4)) = (f32x4){o0[0], o0[1], o1[0], o1[1]};
-    }
-  };
-  auto next_item = [&](Item& it) __attribute__((always_inline)) {      // -> true when the tile changed
-    it.c0 += KC;
-    if (it.c0 < a.Cin) return false;
-    it.c0 = 0;
-    ++it.k;
-    if (it.k < nt_mine) it.t = tile_of(it.k);
-    return true;
-  };
-  // prepare item `it` (whose raw brick is in `vin`) into buffers `buf`; then fetch item `nx` (if any) into `vin`
-  auto prepare = [&](const Item& it, int buf, bool have_next, const Item& nx, bool next_new_tile) __attribute__((always_inline)) {
-    commit();
-    dma_u(it, buf);
-    if (have_next) {
-      if (next_new_tile) plan_tile(nx.t);
-      fetch(nx);
-    }
-    transform_plane(pl, buf);
-    if (lane < 32) transform_plane(4 + pl, buf);
-    // the weight pieces have to be in LDS at the barrier; the raw loads issued after them stay in flight
-    if (have_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSP) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  };
+  // younger loads at the point of use, steady state: the set's own loads were issued two slots ago as [LU(i) F(i+1)],
+  // then came [LU(i+1) F(i+2)]
+  constexpr int VM_AFTER_LU = NSP + 6 + NSP;       // SU(i) waits for LU(i)
+  constexpr int VM_AFTER_F = 6 + NSP;              // C(i + 1) waits for F(i + 1)
 
-  Item cur;
-  cur.k = 0; cur.c0 = 0; cur.t = tile_of(0);
-  plan_tile(cur.t);
-  fetch(cur);
-  Item nx = cur;
-  bool nt = next_item(nx);
-  bool have = nx.k < nt_mine;
-  prepare(cur, 0, have, nx, nt);
-  __syncthreads();                                 // item 0 ready
-#pragma unroll 1
-  for (int m = 0; m < M; ++m) {
-    // the consumers multiply item m; item m + 1 (raw brick in `vin`) goes to the other buffers, item m + 2 is fetched
-    if (m + 1 < M) {
-      cur = nx;
-      nt = next_item(nx);
-      have = nx.k < nt_mine;
-      prepare(cur, (m + 1) & 1, have, nx, nt);
+  // ---- the producer pipeline.  Slot m = the interval between two block barriers in which the consumers multiply item
+  // m.  Beside their MFMA stream a vector-ALU instruction of this wave has to wait for the matrix pipe to drain (~60
+  // cycles for an isolated one, ~5 inside a dense burst; tools/probes/mfma_f32_neighbours.hip).  So ALL vector
+  // arithmetic of a slot -- the 32 packed adds of V = Bt d B for this lane's two patches, the filter multiplies, a new
+  // tile's staging plan -- runs as one burst right behind the barrier, when the matrix pipe is empty anyway (the
+  // consumers wait for their first LDS reads), and everything behind it is data movement:
+  //   slot m:  T(m+1) [scale(m+2)] [plan(m+4)]  |  W(m+1) SU(m+1)  C(m+2) R(m+2)  LU(m+3) F(m+4)  | barrier
+  //   F = raw loads -> vin[set]   C = vin -> this wave's brick in LDS   R = patch rows -> d   T = d -> o (vector burst)
+  //   W = o -> V[buf]             LU = weight loads -> uq[set]          SU = uq -> U[buf]
+  f32x2 d[2][4][2], o[2][4][2];
+  auto read_patches = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float* src = rawp + (q ? patch2_lo : patch_lo);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        d[q][r][0] = *reinterpret_cast<const f32x2*>(src + r * RX);
+        d[q][r][1] = *reinterpret_cast<const f32x2*>(src + r * RX + 2);
+      }
     }
+  };
+  auto transform = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      f32x2 t0, t1, t2, t3;
+      // rows of Bt d: r0 = d0 - d2, r1 = d1 + d2, r2 = d2 - d1, r3 = d1 - d3 (two column pairs each), then per row the
+      // column combinations (t0-t2, t1+t2) and (t2-t1, t1-t3) as one v_pk_add_f32 each (op_sel picks the halves)
+      asm volatile(
+          "v_pk_add_f32 %8, %12, %16 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+          "v_pk_add_f32 %9, %13, %17 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+          "v_pk_add_f32 %10, %14, %16\n\t"
+          "v_pk_add_f32 %11, %15, %17\n\t"
+          "v_pk_add_f32 %0, %8, %9 op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+          "v_pk_add_f32 %1, %9, %8 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]\n\t"
+          "v_pk_add_f32 %2, %10, %11 op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+          "v_pk_add_f32 %3, %11, %10 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]\n\t"
+          "v_pk_add_f32 %8, %16, %14 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+          "v_pk_add_f32 %9, %17, %15 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+          "v_pk_add_f32 %10, %14, %18 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+          "v_pk_add_f32 %11, %15, %19 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+          "v_pk_add_f32 %4, %8, %9 op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+          "v_pk_add_f32 %5, %9, %8 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]\n\t"
+          "v_pk_add_f32 %6, %10, %11 op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+          "v_pk_add_f32 %7, %11, %10 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]"
+          : "=&v"(o[q][0][0]), "=&v"(o[q][0][1]), "=&v"(o[q][1][0]), "=&v"(o[q][1][1]), "=&v"(o[q][2][0]), "=&v"(o[q][2][1]),
+            "=&v"(o[q][3][0]), "=&v"(o[q][3][1]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+          : "v"(d[q][0][0]), "v"(d[q][0][1]), "v"(d[q][1][0]), "v"(d[q][1][1]), "v"(d[q][2][0]), "v"(d[q][2][1]),
+            "v"(d[q][3][0]), "v"(d[q][3][1]));
+    }
+  };
+  float* const v_dst = v_s + pl * V_PLANE + v_row;
+  auto write_v = [&](auto buf_tag) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf_tag)::value;
+    float* dst = v_dst + BUF * V_BUF;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      *reinterpret_cast<f32x4*>(dst + ((r ^ swz) * 4)) = (f32x4){o[0][r][0][0], o[0][r][0][1], o[0][r][1][0], o[0][r][1][1]};
+    if (lane < 32) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<f32x4*>(dst + 4 * V_PLANE + ((r ^ swz) * 4)) =
+            (f32x4){o[1][r][0][0], o[1][r][0][1], o[1][r][1][0], o[1][r][1][1]};
+    }
+  };
+  auto store_ub = [&](auto buf_tag) __attribute__((always_inline)) {       // weights of an item i: set i & 1 -> U[i & 1]
+    constexpr int BUF = decltype(buf_tag)::value;
+    float* ub = u_s + BUF * U_CHUNK + lane * 4;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) *reinterpret_cast<f32x4*>(ub + (p + 4 * q) * 256) = uq[BUF][q];
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+
+  // prologue: item 0 into V[0] / U[0]; d = patches of item 1; weights of items 1, 2 and raw bricks of items 2, 3 on
+  // their way (item i: register set i & 1)
+  Item fi;                                          // the item whose raw brick was fetched last
+  fi.k = 0; fi.c0 = 0; fi.t = tile_of(0);
+  plan_tile(fi.t);
+  fetch(fi, S0{});
+  load_u(fi, S0{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  scale_vin(S0{});
+  commit_raw(S0{});
+  read_patches();
+  transform();
+  write_v(S0{});
+  store_ub(S0{});
+  if (1 < M) {
+    if (next_item(fi)) plan_tile(fi.t);
+    fetch(fi, S1{});
+    load_u(fi, S1{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    scale_vin(S1{});
+    commit_raw(S1{});
+    read_patches();
+    if (2 < M) {
+      if (next_item(fi)) plan_tile(fi.t);
+      fetch(fi, S0{});
+      load_u(fi, S0{});
+      if (3 < M) {
+        if (next_item(fi)) plan_tile(fi.t);
+        fetch(fi, S1{});
+      }
+    }
+  }
+  __syncthreads();                                 // item 0 ready
+
+  auto slot = [&](int m, auto par_tag) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par_tag)::value;  // m & 1: this slot fills buffers (m + 1) & 1 = 1 - PAR
+    using SP = std::integral_constant<int, PAR>;
+    using NB = std::integral_constant<int, 1 - PAR>;
+#ifndef DV_PS_ABLATE_PRODUCER
+    if (wave == 4) PS_STAMP(1, m, 0);
+    // ---- vector burst
+    Item nx = fi;
+    bool new_tile = false;
+#ifndef DV_PS_ABLATE_T
+    if (m + 1 < M) transform();                     // d (item m + 1) -> o
+    if (m + 2 < M) scale_vin(SP{});                 // registers of item m + 2
+#endif
+    if (m + 4 < M) {
+      new_tile = next_item(nx);
+      if (new_tile) plan_tile(nx.t);
+    }
+    if (wave == 4) PS_STAMP(1, m, 1);
+    // ---- data movement only
+    const bool steady = m + 4 < M;                  // every load of the pattern above was really issued
+#ifndef DV_PS_ABLATE_W
+    if (m + 1 < M) {
+      write_v(NB{});
+      if (steady) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_AFTER_LU) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      store_ub(NB{});                               // weights of item m + 1, loaded two slots ago
+    }
+#endif
+    if (wave == 4) PS_STAMP(1, m, 2);
+    if (m + 2 < M) {
+#ifndef DV_PS_ABLATE_C
+      if (steady) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_AFTER_F) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      commit_raw(SP{});                             // brick of item m + 2, fetched two slots ago
+#endif
+#ifndef DV_PS_ABLATE_R
+      read_patches();
+#endif
+    }
+    if (m + 3 < M) load_u(fi, NB{});                // weights of item m + 3 (fi = item m + 3 on entry)
+    if (m + 4 < M) {
+      fi = nx;
+#ifndef DV_PS_ABLATE_F
+      fetch(fi, SP{});                              // brick of item m + 4
+#endif
+    }
+    if (wave == 4) PS_STAMP(1, m, 3);
+#endif
     __syncthreads();
+    if (wave == 4) PS_STAMP(1, m, 6);
+  };
+#pragma unroll 1
+  for (int m = 0; m < M; m += 2) {
+    slot(m, S0{});
+    if (m + 1 < M) slot(m + 1, S1{});
   }
 }
 
@@ -409,6 +599,12 @@ int persistent_grid() {
 }
 
 }  // namespace
+
+#ifdef DV_PS_STAMPS
+extern "C" int dv_ps_read_stamps(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ps_stamps), sizeof(g_ps_stamps));
+}
+#endif
 
 // Same contract as dv_conv3d_wino_f32 (include/diffuvolume_hip.h); `wpacked` from dv_conv3d_wino_pack_weights_f32.
 extern "C" int dv_conv3d_wino_ps_f32(const float* in, const float* wpacked, const float* ch_scale, const float* ch_bias,

@@ -1,13 +1,16 @@
-// Stand-alone A/B of the producer / consumer Winograd kernel (csrc/conv3d_wino_ps.hip) against the all-in-one-wave
+// Stand-alone A/B of the producer / consumer Winograd kernel (tools/experiments/conv3d_wino_ps.hip) against the all-in-one-wave
 // kernel (csrc/conv3d_wino.hip): bitwise comparison of the whole output and timing, no Python, no torch.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -Idiffuvolume_amd/csrc tools/wino_ps_bench.cpp \
-//         diffuvolume_amd/csrc/conv3d_wino.hip diffuvolume_amd/csrc/conv3d_wino_ps.hip -o gpurun_tmp/wino_ps_bench
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -Idiffuvolume_amd/csrc tools/experiments/wino_ps_bench.cpp \
+//         diffuvolume_amd/csrc/conv3d_wino.hip tools/experiments/conv3d_wino_ps.hip -o gpurun_tmp/wino_ps_bench
 //   gpurun_tmp/wino_ps_bench [Cin Cout [D H W [B [scale residual]]]]      (default 32 32 48 128 240, batch 8)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "../include/diffuvolume_hip.h"
+#include "../../include/diffuvolume_hip.h"
+#ifdef DV_PS_STAMPS
+extern "C" int dv_ps_read_stamps(unsigned long long* host);
+#endif
 extern "C" int dv_conv3d_wino_ps_f32(const float*, const float*, const float*, const float*, const float*, const float*,
                                      float*, int, int, int, int, int, int, int, dv_stream_t);
 
@@ -36,11 +39,12 @@ int main(int argc, char** argv) {
   hipMalloc(&sc, Cout * 4); hipMalloc(&bi, Cout * 4);
   {
     std::vector<float> h(nin);
-    for (size_t i = 0; i < nin; ++i) h[i] = (float)((i * 2654435761u) % 1000) / 1000.f - 0.5f;
+    const bool zero = getenv("DV_ZERO_INPUT") != nullptr;     // clock probe: all-zero operands draw less power
+    for (size_t i = 0; i < nin; ++i) h[i] = zero ? 0.f : (float)((i * 2654435761u) % 1000) / 1000.f - 0.5f;
     hipMemcpy(in, h.data(), nin * 4, hipMemcpyHostToDevice);
   }
   std::vector<float> hw((size_t)Cin * Cout * 27);
-  for (size_t i = 0; i < hw.size(); ++i) hw[i] = (float)((i * 40503u) % 977) / 977.f * 0.1f - 0.05f;
+  for (size_t i = 0; i < hw.size(); ++i) hw[i] = getenv("DV_ZERO_WEIGHTS") ? 0.f : (float)((i * 40503u) % 977) / 977.f * 0.1f - 0.05f;
   hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
   std::vector<float> hs(Cout), hb(Cout);
   for (int i = 0; i < Cout; ++i) { hs[i] = 0.8f + 0.01f * i; hb[i] = 0.05f * (i % 7) - 0.1f; }
@@ -87,5 +91,27 @@ int main(int argc, char** argv) {
            (which & 1) ? "producer/consumer" : "all-in-one-wave  ", Cin, Cout, D, H, W, B, use_scale, use_res, ms,
            2.0 * nout * Cin * 27 / ms / 1e9, 2.0 * nout * Cin * 27 / 2.25 / ms / 1e9, 2.0 * nout * Cin * 27 / 2.25 / ms / 1e9 / 157.3);
   }
+#ifdef DV_PS_STAMPS
+  {
+    static unsigned long long st[2][48][8];
+    dv_conv3d_wino_ps_f32(in, wp, sc, bi, isc, res, o2, B, Cin, D, H, W, Cout, 1, 0);
+    hipDeviceSynchronize();
+    dv_ps_read_stamps(&st[0][0][0]);
+    const unsigned long long t0 = st[0][0][0];
+    printf("consumer wave 0 of block 0 (cycles since its first stamp): item: start  compute_end(+d)  barrier_end(+d)  [epilogue_end]\n");
+    for (int m = 0; m < 20; ++m)
+      printf("  C %2d: %8lld  +%6lld  +%6lld  %s%lld\n", m, (long long)(st[0][m][0] - t0), (long long)(st[0][m][1] - st[0][m][0]),
+             (long long)(st[0][m][2] - st[0][m][1]), st[0][m][3] ? "epi +" : "", st[0][m][3] ? (long long)(st[0][m][3] - st[0][m][2]) : 0LL);
+    printf("block 0 consumer wave 0: %llu items in %lld s_memtime ticks = %.1f ticks per item; s_memrealtime (100 MHz) %lld -> %.3f ms, %.3f GHz tick rate\n",
+           st[0][47][6], (long long)(st[0][47][7] - t0), (double)(st[0][47][7] - t0) / (double)st[0][47][6],
+           (long long)(st[0][47][4] - st[0][47][5]), (double)(st[0][47][4] - st[0][47][5]) / 1e5,
+           (double)(st[0][47][7] - st[0][7][3]) / ((double)(st[0][47][4] - st[0][47][5]) * 10.0));
+    printf("producer wave 4, slot m: start  burst  W+SU  C+LU+F  R  -  barrier\n");
+    for (int m = 0; m < 20; ++m)
+      printf("  P %2d: %8lld  +%5lld +%5lld +%5lld +%5lld +%5lld +%5lld\n", m, (long long)(st[1][m][0] - t0),
+             (long long)(st[1][m][1] - st[1][m][0]), (long long)(st[1][m][2] - st[1][m][1]), (long long)(st[1][m][3] - st[1][m][2]),
+             (long long)(st[1][m][4] - st[1][m][3]), (long long)(st[1][m][5] - st[1][m][4]), (long long)(st[1][m][6] - st[1][m][5]));
+  }
+#endif
   return hbad ? 1 : 0;
 }

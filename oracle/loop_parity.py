@@ -109,12 +109,13 @@ def teacher_forced(model, trace, vol_d, used_d, used, gt, **step_kw) -> List[Dic
 
 
 @torch.no_grad()
-def teacher_forced_vs_fp64(model, orc32, orc64, trace, vol, vol_d, used_d, **step_kw) -> List[Dict]:
+def teacher_forced_vs_fp64(model, orc32, orc64, trace, vol, vol_d, used_d, oracle_args=(), **step_kw) -> List[Dict]:
     """Triangulation against a float64 evaluation of the reference's function.  For every step of ``trace`` (the fp32
     oracle's run), from the SAME entering state: disparity of the HIP path, of the fp32 oracle and of the oracle with
     float64 weights and activations.  Returns per step the raw statistics of |HIP - fp64| and |fp32 oracle - fp64|
     (``frac_gt_1e-3`` = the contract's pixel figure, unscaled) -- two fp32 evaluations of a network can agree with
-    each other no better than the sum of their distances to this one."""
+    each other no better than the sum of their distances to this one.  ``oracle_args``: extra positional arguments of
+    the float64 oracle's ``model_predictions`` (the KITTI12 flavour's feature dictionaries, in float64)."""
     dev = vol_d.device
     out = []
     vol64 = vol.double()
@@ -124,7 +125,7 @@ def teacher_forced_vs_fp64(model, orc32, orc64, trace, vol, vol_d, used_d, **ste
         fill = None if r["fill"] is None else r["fill"].to(dev)
         disp_h = model.ddim_step(i, vol_d, used_d, r["img"].to(dev), mask, None, eps, fill, **step_kw)[0].cpu().double()
         t = torch.full((vol.shape[0],), r["time"], dtype=torch.long)
-        _, _, disp64, prob64 = orc64.model_predictions(vol64, r["img"], t)
+        _, _, disp64, prob64 = orc64.model_predictions(vol64, r["img"], t, *oracle_args)
         k = torch.arange(0, prob64.shape[1], dtype=torch.float64).view(1, -1, 1, 1)
         unc64 = torch.sum(torch.abs(disp64.unsqueeze(1) - k) * prob64, dim=1)
         del prob64

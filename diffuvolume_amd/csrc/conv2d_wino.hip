@@ -198,26 +198,31 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
         bq[slot][n] = *reinterpret_cast<const f32x4*>(ub + ((g >> 2) * NT + n) * (4 * 256) + b_lo[g & 3]);
     };
     auto transform = [&](int slot) __attribute__((always_inline)) {   // V = Bt d B, packed fp32 (conv3d_wino.hip)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        f32x2 t0, t1;
-        const int ra = r == 0 ? 0 : (r == 2 ? 2 : 1), rb2 = r == 0 ? 2 : (r == 1 ? 2 : (r == 2 ? 1 : 3));
-        if (r == 1) {
-          asm("v_pk_add_f32 %0, %1, %2" : "=v"(t0) : "v"(d[ra][0]), "v"(d[rb2][0]));
-          asm("v_pk_add_f32 %0, %1, %2" : "=v"(t1) : "v"(d[ra][1]), "v"(d[rb2][1]));
-        } else {
-          asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t0) : "v"(d[ra][0]), "v"(d[rb2][0]));
-          asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t1) : "v"(d[ra][1]), "v"(d[rb2][1]));
-        }
-        // The two results of a row are MFMA A operands.  gfx950 does not interlock a VALU write with an MFMA that reads
-        // the register as SrcA/B within the next two issue slots (probed: v_pk_add_f32 / v_add_f32 -> v_mfma back to back
-        // or one instruction apart reads the OLD value), and the compiler cannot see through inline asm to add the wait
-        // states itself: the s_nop makes the pair safe wherever the scheduler puts the consuming MFMA.
-        asm("v_pk_add_f32 %0, %2, %3 op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
-            "v_pk_add_f32 %1, %3, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]\n\t"
-            "s_nop 1"
-            : "=&v"(vp[slot][r][0]), "=&v"(vp[slot][r][1]) : "v"(t0), "v"(t1));
-      }
+      // one asm statement = one dense burst of 16 packed adds (a vector instruction that arrives alone between two fp32
+      // MFMAs makes the shared pipe drain, ~60 cycles; ~5 inside a burst); the closing s_nop covers the VALU -> MFMA
+      // read hazard that gfx950 does not interlock (conv3d_wino.hip)
+      f32x2 t0, t1, t2, t3;
+      asm("v_pk_add_f32 %8, %12, %16 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+          "v_pk_add_f32 %9, %13, %17 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+          "v_pk_add_f32 %10, %14, %16\n\t"
+          "v_pk_add_f32 %11, %15, %17\n\t"
+          "v_pk_add_f32 %0, %8, %9 op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+          "v_pk_add_f32 %1, %9, %8 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]\n\t"
+          "v_pk_add_f32 %2, %10, %11 op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+          "v_pk_add_f32 %3, %11, %10 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]\n\t"
+          "v_pk_add_f32 %8, %16, %14 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+          "v_pk_add_f32 %9, %17, %15 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+          "v_pk_add_f32 %10, %14, %18 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+          "v_pk_add_f32 %11, %15, %19 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+          "v_pk_add_f32 %4, %8, %9 op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+          "v_pk_add_f32 %5, %9, %8 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]\n\t"
+          "v_pk_add_f32 %6, %10, %11 op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+          "v_pk_add_f32 %7, %11, %10 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]\n\t"
+          "s_nop 1"
+          : "=&v"(vp[slot][0][0]), "=&v"(vp[slot][0][1]), "=&v"(vp[slot][1][0]), "=&v"(vp[slot][1][1]),
+            "=&v"(vp[slot][2][0]), "=&v"(vp[slot][2][1]), "=&v"(vp[slot][3][0]), "=&v"(vp[slot][3][1]),
+            "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+          : "v"(d[0][0]), "v"(d[0][1]), "v"(d[1][0]), "v"(d[1][1]), "v"(d[2][0]), "v"(d[2][1]), "v"(d[3][0]), "v"(d[3][1]));
     };
     load_patch(0);
     load_b(0, 0);

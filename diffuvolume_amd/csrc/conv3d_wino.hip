@@ -271,28 +271,43 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
     // (Round 2 A/B: the same transform as 32 pinned single-register v_add_f32 / v_sub_f32, no moves, measured 1.9 %
     // SLOWER on the 32->32 layer -- 58.5 vs 57.35 ms per step -- so the packed form stays.)
     auto transform = [&](int slot) __attribute__((always_inline)) {
+      // The 16 packed adds of a patch are ONE asm statement (one dense burst; measured the same speed as the scheduler's
+      // own spreading of them over the MFMA stream, and one statement is easier to reason about).  Rows of Bt d:
+      // r0 = d0 - d2, r1 = d1 + d2, r2 = d2 - d1, r3 = d1 - d3 (two column pairs each), then per row the column
+      // combinations (t0-t2, t1+t2) and (t2-t1, t1-t3) as one v_pk_add_f32 each (op_sel picks the halves, neg_* the
+      // signs) -- 16 vector instructions per patch instead of 32 adds plus the moves the compiler puts around them.
+      // (Round 2 A/B: the same transform as 32 pinned single-register v_add_f32 / v_sub_f32, no moves, measured 1.9 %
+      // SLOWER on the 32->32 layer -- 58.5 vs 57.35 ms per step -- so the packed form stays.)
+      // The results are MFMA A operands.  gfx950 does not interlock a VALU write with an MFMA that reads the register
+      // as SrcA/B within the next two issue slots (probed: v_pk_add_f32 / v_add_f32 -> v_mfma back to back or one
+      // instruction apart reads the OLD value), and the compiler cannot see through inline asm to add the wait states
+      // itself: the closing s_nop makes the burst safe wherever the scheduler puts the consuming MFMA.
 #pragma unroll
-      for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          f32x2 t0, t1;
-          const int ra = r == 0 ? 0 : (r == 2 ? 2 : 1), rb2 = r == 0 ? 2 : (r == 1 ? 2 : (r == 2 ? 1 : 3));
-          if (r == 1) {
-            asm("v_pk_add_f32 %0, %1, %2" : "=v"(t0) : "v"(d[mt][ra][0]), "v"(d[mt][rb2][0]));
-            asm("v_pk_add_f32 %0, %1, %2" : "=v"(t1) : "v"(d[mt][ra][1]), "v"(d[mt][rb2][1]));
-          } else {
-            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t0) : "v"(d[mt][ra][0]), "v"(d[mt][rb2][0]));
-            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t1) : "v"(d[mt][ra][1]), "v"(d[mt][rb2][1]));
-          }
-          // The two results of a row are MFMA A operands.  gfx950 does not interlock a VALU write with an MFMA that reads
-          // the register as SrcA/B within the next two issue slots (probed: v_pk_add_f32 / v_add_f32 -> v_mfma back to back
-          // or one instruction apart reads the OLD value), and the compiler cannot see through inline asm to add the wait
-          // states itself: the s_nop makes the pair safe wherever the scheduler puts the consuming MFMA.
-          asm("v_pk_add_f32 %0, %2, %3 op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
-              "v_pk_add_f32 %1, %3, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]\n\t"
-              "s_nop 1"
-              : "=&v"(vp[mt][slot][r][0]), "=&v"(vp[mt][slot][r][1]) : "v"(t0), "v"(t1));
-        }
+      for (int mt = 0; mt < MTW; ++mt) {
+        f32x2 t0, t1, t2, t3;
+        asm("v_pk_add_f32 %8, %12, %16 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %9, %13, %17 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %10, %14, %16\n\t"
+            "v_pk_add_f32 %11, %15, %17\n\t"
+            "v_pk_add_f32 %0, %8, %9 op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+            "v_pk_add_f32 %1, %9, %8 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]\n\t"
+            "v_pk_add_f32 %2, %10, %11 op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+            "v_pk_add_f32 %3, %11, %10 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]\n\t"
+            "v_pk_add_f32 %8, %16, %14 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %9, %17, %15 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %10, %14, %18 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %11, %15, %19 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %4, %8, %9 op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+            "v_pk_add_f32 %5, %9, %8 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]\n\t"
+            "v_pk_add_f32 %6, %10, %11 op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+            "v_pk_add_f32 %7, %11, %10 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]\n\t"
+            "s_nop 1"
+            : "=&v"(vp[mt][slot][0][0]), "=&v"(vp[mt][slot][0][1]), "=&v"(vp[mt][slot][1][0]), "=&v"(vp[mt][slot][1][1]),
+              "=&v"(vp[mt][slot][2][0]), "=&v"(vp[mt][slot][2][1]), "=&v"(vp[mt][slot][3][0]), "=&v"(vp[mt][slot][3][1]),
+              "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+            : "v"(d[mt][0][0]), "v"(d[mt][0][1]), "v"(d[mt][1][0]), "v"(d[mt][1][1]), "v"(d[mt][2][0]), "v"(d[mt][2][1]),
+              "v"(d[mt][3][0]), "v"(d[mt][3][1]));
+      }
     };
     load_patch(0);
     load_b(0, 0);

@@ -36,6 +36,9 @@ SIGNATURES = {
     "dv_gwc_volume_f32": (c_int, [P, P, P, I, I, I, I, I, I, P]),
     "dv_concat_volume_f32": (c_int, [P, P, P, I, I, I, I, I, I, P]),
     "dv_concat_attn_volume_f32": (c_int, [P, P, P, P, I, I, I, I, I, P]),
+    "dv_softmax_d_f32": (c_int, [P, P, I, I, I, P]),
+    "dv_mul_f32": (c_int, [P, P, P, c_size_t, P]),
+    "dv_conv3d_rank1_filter_f32": (c_int, [P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "dv_noise_prepare_f32": (c_int, [P, P, P, I, I, I, P]),
     "dv_noise_prepare_f64": (c_int, [P, P, P, P, I, I, I, P]),
     "dv_conv3d_packed_floats": (c_size_t, [I, I, I]),

@@ -27,7 +27,8 @@ from torch import nn
 
 from . import _lib
 from .head import DynamicHead
-from .submodule import (ACT_NONE, ACT_RELU, Conv2dPlan, Conv3dPlan, Deconv3dPlan, ReplicaPlanCache, _dev_f32,
+from .submodule import (ACT_NONE, ACT_RELU, Conv2dPlan, Conv3dPlan, Deconv3dPlan, Rank1FilterPlan, ReplicaPlanCache,
+                        _dev_f32,
                         build_concat_attention_volume, build_gwc_volume, check_split_overflow,
                         default_conv_precision, patch_volume, upsample_softmax_regress, window_attention)
 
@@ -232,6 +233,10 @@ class _HourglassPlan:
         return self.conv6(c5, skip=x)                      # relu(deconv+bn + redir1(x))
 
 
+# A/B switch for tools/ and tests: False keeps the first layer of a DDIM step on the generic filtered convolution
+RANK1_FILTER = True
+
+
 class _ConvPairPlan:
     """convbn-ReLU-conv[bn][-ReLU] stacks (dres0 / dres1 / classif*, acv_ddim.py:200-222)."""
 
@@ -247,10 +252,19 @@ class _ConvPairPlan:
         y = self.a(x, in_scale=in_scale)
         return self.b(y, residual=x if residual_self else None)
 
+    def second(self, y):
+        return self.b(y)
+
 
 class _Plans:
     def __init__(self, m: "ACVNet_DDIM"):
         self.dres0 = _ConvPairPlan(m.dres0, relu_last=True)
+        # dres0[0] on the factors of a filtered attention-concat volume (acv_ddim.py:260, :388-390); exact-fp32 paths only
+        conv0, bn0 = m.dres0[0][0], m.dres0[0][1]
+        self.dres0_rank1 = None
+        if default_conv_precision() in ("f32", "f32_direct") and RANK1_FILTER:
+            self.dres0_rank1 = Rank1FilterPlan(conv0.weight, (bn0.weight, bn0.bias, bn0.running_mean, bn0.running_var),
+                                               act=ACT_RELU, eps=bn0.eps)
         self.dres1 = _ConvPairPlan(m.dres1, relu_last=False)
         self.dres2 = _HourglassPlan(m.dres2)
         self.dres3 = _HourglassPlan(m.dres3)
@@ -481,7 +495,11 @@ class ACVNet_DDIM(_HipPlanMixin):
     def _aggregate(self, volume: torch.Tensor, n01f: Optional[torch.Tensor]) -> torch.Tensor:
         """acv_ddim.py:260-266: (volume * filter) -> dres0 -> dres1(+res) -> dres2 -> dres3 -> classif2."""
         p = self.prepare()
-        cost0 = p.dres0(volume, in_scale=n01f)
+        r1 = getattr(p, "dres0_rank1", None)
+        if r1 is not None and n01f is not None and r1.applies(volume):
+            cost0 = p.dres0.second(r1(volume, n01f))            # first layer on the volume's factors (Rank1FilterPlan)
+        else:
+            cost0 = p.dres0(volume, in_scale=n01f)
         cost0 = p.dres1(cost0, residual_self=True)
         out2 = p.dres3(p.dres2(cost0))
         return p.classif2(out2)

@@ -190,6 +190,12 @@ def build_concat_attention_volume(refimg_fea: torch.Tensor, targetimg_fea: torch
               lambda: _lib.check(lib.dv_concat_attn_volume_f32(ref.data_ptr(), tgt.data_ptr(), att.data_ptr(),
                                                                out.data_ptr(), b, c, h, w, maxdisp,
                                                                _lib.stream_ptr()), "dv_concat_attn_volume_f32"))
+        # the factors of this volume (softmax(att) and the two feature maps) ride along: the first aggregation layer
+        # of every DDIM step can then run on them instead of on the 64-channel volume (Rank1FilterPlan)
+        p_att = torch.empty((b, maxdisp, h, w), dtype=torch.float32, device=ref.device)
+        _lib.check(lib.dv_softmax_d_f32(att.data_ptr(), p_att.data_ptr(), b, maxdisp, h * w, _lib.stream_ptr()),
+                   "dv_softmax_d_f32")
+    out._dv_factors = (p_att, ref, tgt)
     return out
 
 
@@ -399,6 +405,69 @@ class ReplicaPlanCache:
 
     def _replica_clear(self):
         self.__dict__.pop("_replica_plans", None)
+
+
+class Rank1FilterPlan:
+    """The first layer of a DiffuVolume step, ``relu(bn(conv3d(volume * noise)))`` (acv_ddim.py:260 + dres0[0],
+    :200-203), on the FACTORS of its input instead of the [B,64,48,h,w] volume: with volume = p * [L ; R(x-d)]
+    (p = softmax(att), :388-390) and noise a per-voxel scalar the convolution is
+    ``sum_tap (p*noise)(.) * (GL[tap] + GR[tap](x - d))``, GL / GR = 1x1 convolutions of L / R with the layer's weights,
+    built once per stereo pair (csrc/rank1_filter.hip): 54 instead of 1728 multiply-adds per output, the same function
+    up to fp32 re-association.  Used by ``ACVNet_DDIM`` whenever the volume it is handed carries its factors
+    (``build_concat_attention_volume`` attaches them); any other volume takes the generic convolution."""
+
+    MAX_D = 48
+
+    def __init__(self, weight: torch.Tensor, bn, act: int = ACT_RELU, eps: float = 1e-5):
+        w = _dev_f32(weight.detach(), "weight")
+        self.cout, cin2, k = w.shape[0], w.shape[1], w.shape[2]
+        if tuple(w.shape[2:]) != (3, 3, 3) or cin2 % 2:
+            raise _lib.DiffuVolumeError("Rank1FilterPlan: a 3x3x3 convolution over [left | right] channel halves")
+        self.c = cin2 // 2
+        self.act = act
+        # table weights: output channel = tap * Cout + co
+        wl = w[:, :self.c].permute(2, 3, 4, 0, 1).reshape(27 * self.cout, self.c, 1, 1).contiguous()
+        wr = w[:, self.c:].permute(2, 3, 4, 0, 1).reshape(27 * self.cout, self.c, 1, 1).contiguous()
+        self.table_l = Conv2dPlan(wl, None, act=ACT_NONE)
+        self.table_r = Conv2dPlan(wr, None, act=ACT_NONE)
+        self.scale, self.shift = _fold_bn(bn, None, self.cout, w.device, eps)
+
+    def applies(self, volume: torch.Tensor) -> bool:
+        fac = getattr(volume, "_dv_factors", None)
+        return (fac is not None and volume.dim() == 5 and volume.shape[1] == 2 * self.c and volume.shape[2] <= self.MAX_D
+                and fac[1].shape[1] == self.c and tuple(fac[0].shape) == (volume.shape[0],) + tuple(volume.shape[2:]))
+
+    def tables(self, volume: torch.Tensor):
+        """(GL, GR) [B, 27*Cout, h, w] of a volume's feature maps, cached on the volume object."""
+        cached = getattr(volume, "_dv_rank1_tables", None)
+        if cached is not None and cached[0] is self:
+            return cached[1], cached[2]
+        _, ref, tgt = volume._dv_factors
+        gl, gr = self.table_l(ref), self.table_r(tgt)
+        volume._dv_rank1_tables = (self, gl, gr)
+        return gl, gr
+
+    def __call__(self, volume: torch.Tensor, noise01: torch.Tensor) -> torch.Tensor:
+        p_att = volume._dv_factors[0]
+        noise01 = _dev_f32(noise01, "noise01")
+        b, d, h, w = p_att.shape
+        if noise01.numel() != p_att.numel():
+            raise RuntimeError("the filter must be [B,D,H,W]")
+        gl, gr = self.tables(volume)
+        s = torch.empty_like(p_att)
+        out = torch.empty((b, self.cout, d, h, w), dtype=torch.float32, device=p_att.device)
+        lib = _lib.load()
+        with torch.cuda.device(p_att.device):
+            _lib.check(lib.dv_mul_f32(p_att.data_ptr(), noise01.data_ptr(), s.data_ptr(), s.numel(), _lib.stream_ptr()),
+                       "dv_mul_f32")
+            # algorithmic flops / bytes of the layer it replaces (SURVEY 8d); issued on the vector ALU, not the matrix pipe
+            timed(f"conv3d_k3s1_co{self.cout}_filter_rank1", 2.0 * out.numel() * 2 * self.c * 27,
+                  4.0 * (volume.numel() + out.numel() + s.numel()),
+                  lambda: _lib.check(lib.dv_conv3d_rank1_filter_f32(s.data_ptr(), gl.data_ptr(), gr.data_ptr(),
+                                                                    _lib.ptr(self.scale), _lib.ptr(self.shift),
+                                                                    out.data_ptr(), b, d, h, w, self.cout, self.act,
+                                                                    _lib.stream_ptr()), "dv_conv3d_rank1_filter_f32"))
+        return out
 
 
 class Conv2dPlan:

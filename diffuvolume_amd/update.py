@@ -106,11 +106,16 @@ class BasicMotionEncoder(_Planned):
         return {n: _plan(getattr(self, n), ACT_RELU) for n in ("convc1", "convc2", "convd2", "conv")}
 
     def forward(self, disp, corr):
+        return torch.cat(self.features(disp, corr), dim=1)           # update.py:94 (the reference's return value)
+
+    def features(self, disp, corr):
+        """The two halves of the motion features, (conv output [B,127,h,w], disp [B,1,h,w]): the update block hands
+        them to gru04 as two sources of its virtual concatenation instead of materialising torch.cat per iteration."""
         p = self.plans()
         cor = p["convc2"](p["convc1"](corr))
         disp_ = p["convd2"](self._convd1(disp))
         out = p["conv"]([cor, disp_])                   # virtual concatenation: torch.cat([cor, disp_]) is never materialised
-        return torch.cat([out, disp], dim=1)
+        return out, disp.contiguous()
 
     def _convd1(self, disp):
         """relu(convd1(disp)): the 7x7 single-input-channel convolution on its own VALU kernel (MIOpen picks a naive
@@ -192,11 +197,11 @@ class BasicMultiUpdateBlock(_Planned):
                 else:
                     net[1] = self.gru08(net[1], *(inp[1]), pool2x(net[0]))
             if iter04:
-                motion_features = self.encoder(disp, corr)
+                mf, dsp = self.encoder.features(disp, corr)          # [h | mf | disp | interp]: four sources, no cat
                 if self.args.n_gru_layers > 1:
-                    net[0] = self.gru04(net[0], *(inp[0]), motion_features, interp(net[1], net[0]))
+                    net[0] = self.gru04(net[0], *(inp[0]), mf, dsp, interp(net[1], net[0]))
                 else:
-                    net[0] = self.gru04(net[0], *(inp[0]), motion_features)
+                    net[0] = self.gru04(net[0], *(inp[0]), mf, dsp)
             if not update:
                 return net
             delta_disp = self.disp_head(net[0])

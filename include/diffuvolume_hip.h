@@ -58,6 +58,21 @@ int dv_concat_volume_f32(const float* ref, const float* tgt, float* out,
 int dv_concat_attn_volume_f32(const float* ref, const float* tgt, const float* att, float* out,
                               int B, int C, int H, int W, int D, dv_stream_t stream);
 
+/* ---- the first aggregation layer of a DiffuVolume step on its factored input --------------------------------
+ * SceneFlow/models/acv_ddim.py:254-262 feeds `volume * noise` to dres0[0] (convbn_3d(64,32,3,1,1) + ReLU, :200-203)
+ * with volume = softmax(att, dim=2) * build_concat_volume(L, R) (:388-390) and noise a per-voxel scalar: the input is
+ * s(b,d,y,x) * [L(y,x) ; R(y,x-d)], so the 3x3x3 convolution is sum_tap s(.) * (GL[tap] + GR[tap](x-d)) with GL / GR
+ * the 1x1 convolutions of L / R with the layer's weights, built once per stereo pair (csrc/rank1_filter.hip).
+ * dv_softmax_d_f32: att [B,D,HW] logits -> p [B,D,HW] = softmax over D (the arithmetic of dv_concat_attn_volume_f32).
+ * dv_mul_f32: out = x * y elementwise (s = p * n01).
+ * dv_conv3d_rank1_filter_f32: s [B,D,H,W], gl / gr [B,27*Cout,H,W] (channel = tap*Cout + co, tap = (kd*3+ky)*3+kx)
+ *   -> out [B,Cout,D,H,W] = act(scale * conv + bias); D <= 48. */
+int dv_softmax_d_f32(const float* att, float* p, int B, int D, int HW, dv_stream_t stream);
+int dv_mul_f32(const float* x, const float* y, float* out, size_t n, dv_stream_t stream);
+int dv_conv3d_rank1_filter_f32(const float* s, const float* gl, const float* gr, const float* ch_scale,
+                               const float* ch_bias, float* out, int B, int D, int H, int W, int Cout, int act,
+                               dv_stream_t stream);
+
 /* ---- time-shifted noise -> [0,1] volume filter ----------------------------
  * DynamicHead add (SceneFlow/models/head.py:74-77) + clamp + rescale
  * (acv_ddim.py:256-258).  x_t [B,C,HW], shift [B,C] (fp32, the MLP output),

@@ -50,7 +50,6 @@ WINO_MULT_REDUCTION = 2.25        # F(2x2,3x3) in-plane: 16 multiplies per 2x2 o
 SIDE_KERNELS = [
     (("deconv3d_k3s2_redir",), "deconv3d_mfma_kernel<3, 8>", 1.0),
     (("conv3d_k3s2_co64", "conv3d_k3s2_co128"), "conv3d_mfma_kernel<Geo<3, 2, 4, 2, 4, 2, 4, 2>, true>", 1.0),
-    (("conv3d_k3s1_co32_filter",), "conv3d_wino_kernel<true, 1, 0>", WINO_MULT_REDUCTION),
     (("conv3d_k3s1_co64",), "conv3d_wino_kernel<false, 1, 1>", WINO_MULT_REDUCTION),
     (("conv3d_k3s1_co128",), "conv3d_wino_kernel<false, 1, 2>", WINO_MULT_REDUCTION),
 ]
@@ -548,6 +547,18 @@ def main():
                          "algorithmic_tflops": fl / ms / 1e9, "multiply_reduction": div,
                          "algorithmic_bytes_per_launch": ab, "traffic": tr,
                          "traffic_over_algorithmic": None if tr is None else tr / ab})
+        # the first layer of every step on the factors of its input (csrc/rank1_filter.hip): vector-ALU / LDS bound
+        r1 = ks.get("conv3d_k3s1_co32_filter_rank1")
+        if r1:
+            side.append({"kernel": "rank1_filter_conv_kernel<2>", "tags": ["conv3d_k3s1_co32_filter_rank1"], "bound": "valu",
+                         "launches": r1["launches"], "avg_ms": r1["total_ms"] / r1["launches"],
+                         "ms_per_step": r1["total_ms"] / a.steps, "achieved": r1["valu_flops"] / r1["total_ms"] / 1e9,
+                         "unit": "TFLOP/s", "peak": PEAK_MFMA_F32_TFLOPS, "frac": r1["valu_flops"] / r1["total_ms"] / 1e9 / PEAK_MFMA_F32_TFLOPS,
+                         "algorithmic_tflops": r1["flops"] / r1["total_ms"] / 1e9,
+                         "note": "dres0[0] of acv_ddim.py:200-203 on s * [L ; R(x-d)]: 81 vector flops per output instead of "
+                                 "3456 matrix flops; algorithmic_tflops counts the layer it replaces (SURVEY 8d), peak = "
+                                 "packed-fp32 vector rate (the same pipe as the fp32 MFMA)",
+                         "traffic": pmc_traffic("rank1_filter_conv_kernel<2>")})
         out["roofline_kernels"] = side
         # whole path against the matrix pipe: flops the kernels ISSUE (Winograd layers: algorithmic / 2.25; vector-ALU
         # kernels: 0) over the wall time of the `value` pass

@@ -496,7 +496,7 @@ class ACVNet_DDIM(_HipPlanMixin):
         """acv_ddim.py:260-266: (volume * filter) -> dres0 -> dres1(+res) -> dres2 -> dres3 -> classif2."""
         p = self.prepare()
         r1 = getattr(p, "dres0_rank1", None)
-        if r1 is not None and n01f is not None and r1.applies(volume):
+        if r1 is not None and r1.applies(volume):
             cost0 = p.dres0.second(r1(volume, n01f))            # first layer on the volume's factors (Rank1FilterPlan)
         else:
             cost0 = p.dres0(volume, in_scale=n01f)

@@ -74,42 +74,81 @@ __global__ __launch_bounds__(R1_XT, CPT == 4 ? 1 : 2) void rank1_filter_conv_ker
   const float* grb = a.gr + ((size_t)b * 27 * a.Cout) * plane;
   const float* sb = a.s + (size_t)b * a.D * plane;
 
-  // ---- GR rows -> LDS: slot ui <-> u = x0 - (D - 1) - 2 + ui; value 0 for u outside [0, W) or y' outside the image
+  // ---- GR rows -> LDS: slot ui <-> u = x0 - (D - 1) - 2 + ui; value 0 for u outside [0, W) or y' outside the image.
+  // Buffer loads (descriptor = this batch item's table, lane offset 2^31 where the value is 0 by definition), nine
+  // taps = 18 x CPT independent loads in flight before the first LDS store: the fill is a latency chain otherwise
+  // (one L2 round trip per slot), and it is a fifth of the block's memory instructions.
   const int umin = x0 - (a.D - 1) - 2;
-#pragma unroll 3
-  for (int tap = 0; tap < 27; ++tap) {
-    const int yy = y + (tap / 3) % 3 - 1;
-    const bool yok = (unsigned)yy < (unsigned)a.H;
-    const float* row = grb + ((size_t)tap * a.Cout + co0) * plane + (size_t)(yok ? yy : 0) * a.W;
+  constexpr int NK = (UW + R1_XT - 1) / R1_XT;
+  const int tab_bytes = __builtin_amdgcn_readfirstlane((int)((size_t)27 * a.Cout * plane * sizeof(float)));   // < 2^31 (host check)
+  const int plane_b = __builtin_amdgcn_readfirstlane((int)(plane * sizeof(float)));
+  auto table_rsrc = [&](const float* base) __attribute__((always_inline)) {
+    const uint64_t p64 = reinterpret_cast<uint64_t>(base);
+    const uint64_t ps = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p64) |
+                        ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(p64 >> 32)) << 32);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(ps), 0, tab_bytes, 0x00020000);
+  };
+  const auto gr_rs = table_rsrc(grb);
+  int uoff[NK];
 #pragma unroll
-    for (int k = 0; k < (UW + R1_XT - 1) / R1_XT; ++k) {
-      const int ui = tid + k * R1_XT, u = umin + ui;
-      if (ui < UW) {
-        vec v = {};
-        if (yok && (unsigned)u < (unsigned)a.W) {
+  for (int k = 0; k < NK; ++k) {
+    const int u = umin + tid + k * R1_XT;
+    uoff[k] = (tid + k * R1_XT < UW && (unsigned)u < (unsigned)a.W) ? u * 4 : (int)0x80000000u;
+  }
+#pragma unroll 1
+  for (int t9 = 0; t9 < 27; t9 += 9) {
+    float v[9][NK][CPT];
 #pragma unroll
-          for (int c = 0; c < CPT; ++c)
-            if (co0 + c < a.Cout) v[c] = row[(size_t)c * plane + u];
-        }
-        reinterpret_cast<vec*>(gr_s)[tap * UW + ui] = v;
+    for (int i = 0; i < 9; ++i) {
+      const int tap = t9 + i;
+      const int yy = y + (tap / 3) % 3 - 1;
+      const bool yok = (unsigned)yy < (unsigned)a.H;
+      // scalar part: channel (tap * Cout + co0 + c) and row yy; rows outside the image: the invalid lane offset
+      const int so = yok ? (tap * a.Cout + co0) * plane_b + yy * a.W * 4 : 0;
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const int vo = yok ? uoff[k] : (int)0x80000000u;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c)
+          v[i][k][c] = (co0 + c < a.Cout)
+                           ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr_rs, vo, so + c * plane_b, 0))
+                           : 0.f;
       }
     }
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const int ui = tid + k * R1_XT;
+        if (ui < UW) {
+          vec q;
+#pragma unroll
+          for (int c = 0; c < CPT; ++c) q[c] = v[i][k][c];
+          reinterpret_cast<vec*>(gr_s)[(t9 + i) * UW + ui] = q;
+        }
+      }
   }
 
-  // ---- GL: 27 x 4 registers, constant over d
+  // ---- GL: 27 x CPT registers, constant over d (branch-free buffer loads like the fill above)
+  const auto gl_rs = table_rsrc(glb);
   vec gl[27];
+  {
+    int goff[9];
 #pragma unroll
-  for (int tap = 0; tap < 27; ++tap) {
-    const int ty = (tap / 3) % 3, txx = tap % 3;
-    const int yy = y + ty - 1, xx = x + txx - 1;
-    vec v = {};
-    if ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) {
-      const float* src = glb + ((size_t)tap * a.Cout + co0) * plane + (size_t)yy * a.W + xx;
+    for (int q = 0; q < 9; ++q) {
+      const int yy = y + q / 3 - 1, xx = x + q % 3 - 1;
+      goff[q] = ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) ? (yy * a.W + xx) * 4 : (int)0x80000000u;
+    }
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      const int so = (tap * a.Cout + co0) * plane_b;
+      vec v = {};
 #pragma unroll
       for (int c = 0; c < CPT; ++c)
-        if (co0 + c < a.Cout) v[c] = src[(size_t)c * plane];
+        if (co0 + c < a.Cout)
+          v[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gl_rs, goff[tap % 9], so + c * plane_b, 0));
+      gl[tap] = v;
     }
-    gl[tap] = v;
   }
 
   // ---- rolling 3 x 3 x 3 window of s: plane p of the window = s(d + p - 1, y + ty - 1, x + tx - 1), q = ty*3 + tx.
@@ -126,16 +165,20 @@ __global__ __launch_bounds__(R1_XT, CPT == 4 ? 1 : 2) void rank1_filter_conv_ker
   const uint64_t sp64 = reinterpret_cast<uint64_t>(sb);
   const uint64_t sps = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sp64) |
                        ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sp64 >> 32)) << 32);
-  auto load_plane = [&](int d, float* dst) __attribute__((always_inline)) {
+  auto load_plane = [&](int d, f32x2* dst) __attribute__((always_inline)) {
     const bool dok = (unsigned)d < (unsigned)a.D;
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(sps), 0, dok ? a.D * plane_bytes : 0, 0x00020000);
     const int so = dok ? d * plane_bytes : 0;
 #pragma unroll
-    for (int q = 0; q < 9; ++q) dst[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, roff[q], so, 0));
+    for (int q = 0; q < 9; ++q) dst[q][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, roff[q], so, 0));
   };
-  float sw[3][9];
+  // (a window value lives in the low half of a register pair: the packed fma below broadcasts it to both channels
+  // through op_sel instead of a move per tap)
+  f32x2 sw[3][9];
 #pragma unroll
-  for (int q = 0; q < 9; ++q) sw[0][q] = 0.f;       // plane -1
+  for (int p3 = 0; p3 < 3; ++p3)
+#pragma unroll
+    for (int q = 0; q < 9; ++q) sw[p3][q] = (f32x2){0.f, 0.f};       // plane -1 stays zero
   load_plane(0, sw[1]);
   load_plane(1, sw[2]);
 
@@ -169,16 +212,34 @@ __global__ __launch_bounds__(R1_XT, CPT == 4 ? 1 : 2) void rank1_filter_conv_ker
   const vec* grq = reinterpret_cast<const vec*>(gr_s) + tid + (a.D - 1) + 2;
   // one step: planes (pa, pb, pc) of the window are (d - 1, d, d + 1); plane d + 2 is requested into pa's registers
   // once they have been read (three steps per trip: the window rotates through its three register sets, no moves)
-  auto step = [&](int d, float* pa, float* pb, float* pc) __attribute__((always_inline)) {
-    vec acc = {};
+  auto mac = [&](vec& acc, const f32x2& sv, const vec& g) __attribute__((always_inline)) {
+    if constexpr (CPT == 2) {
+      asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(g), "v"(sv));
+    } else {
+      acc += sv[0] * g;
+    }
+  };
+  auto step = [&](int d, f32x2* pa, f32x2* pb, f32x2* pc) __attribute__((always_inline)) {
+    // all 27 LDS reads of the step first (two waves per SIMD: latencies are hidden by issuing early, not by other
+    // waves), three independent accumulation chains, the next plane of s requested as soon as plane d - 1 is consumed
     const vec* gq = grq - d;
+    vec g[27];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) acc += pa[q] * (gl[q] + gq[q * UW + q % 3]);
+    for (int q = 0; q < 9; ++q) {
+      g[q] = gq[q * UW + q % 3];
+      g[9 + q] = gq[(9 + q) * UW + q % 3 - 1];
+      g[18 + q] = gq[(18 + q) * UW + q % 3 - 2];
+    }
+    vec acc0 = {}, acc1 = {}, acc2 = {};
+#pragma unroll
+    for (int q = 0; q < 9; ++q) mac(acc0, pa[q], gl[q] + g[q]);
     load_plane(d + 2, pa);
 #pragma unroll
-    for (int q = 0; q < 9; ++q) acc += pb[q] * (gl[9 + q] + gq[(9 + q) * UW + q % 3 - 1]);
-#pragma unroll
-    for (int q = 0; q < 9; ++q) acc += pc[q] * (gl[18 + q] + gq[(18 + q) * UW + q % 3 - 2]);
+    for (int q = 0; q < 9; ++q) {
+      mac(acc1, pb[q], gl[9 + q] + g[9 + q]);
+      mac(acc2, pc[q], gl[18 + q] + g[18 + q]);
+    }
+    const vec acc = acc0 + acc1 + acc2;
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
       float v = fmaf(acc[c], sc[c], bi[c]);
@@ -252,6 +313,9 @@ extern "C" int dv_conv3d_rank1_filter_f32(const float* s, const float* gl, const
   a.ntx = (W + R1_XT - 1) / R1_XT;
   a.ncg = (Cout + CPT - 1) / CPT;
   DV_REQUIRE(D <= R1_DMAX, DV_ERR_UNSUPPORTED);               // the LDS image is sized for 48 disparities
+  DV_REQUIRE((size_t)27 * Cout * H * W * sizeof(float) <= 0x7fffffffull, DV_ERR_SHAPE);    // 31-bit offsets in a table
+  DV_REQUIRE((size_t)Cout * D * H * W * sizeof(float) <= 0x7fffffffull && (size_t)D * H * W * sizeof(float) <= 0x7fffffffull,
+             DV_ERR_SHAPE);
   const long long blocks = (long long)B * H * a.ntx * a.ncg;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return DV_ERR_SHAPE;
   hipLaunchKernelGGL(rank1_filter_conv_kernel<CPT>, dim3((unsigned)blocks), dim3(R1_XT), 0, (hipStream_t)stream, a);

@@ -14,13 +14,14 @@ class KernelTimer:
     def __init__(self):
         self.records = defaultdict(list)     # tag -> [(start, end, flops, bytes, issued matrix-pipe flops)]
 
-    def launch(self, tag: str, flops: float, nbytes: float, fn: Callable[[], None], issued: float = 0.0) -> None:
+    def launch(self, tag: str, flops: float, nbytes: float, fn: Callable[[], None], issued: float = 0.0,
+               valu: float = 0.0) -> None:
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
         s.record()
         fn()
         e.record()
-        self.records[tag].append((s, e, flops, nbytes, issued))
+        self.records[tag].append((s, e, flops, nbytes, issued, valu))
 
     def summary(self) -> Dict[str, dict]:
         torch.cuda.synchronize()
@@ -29,18 +30,19 @@ class KernelTimer:
             ms = sum(r[0].elapsed_time(r[1]) for r in recs)
             out[tag] = {"launches": len(recs), "total_ms": ms, "avg_ms": ms / len(recs),
                         "flops": sum(r[2] for r in recs), "bytes": sum(r[3] for r in recs),
-                        "issued_flops": sum(r[4] for r in recs)}
+                        "issued_flops": sum(r[4] for r in recs), "valu_flops": sum(r[5] for r in recs)}
         return out
 
 
 WINO_MULT_REDUCTION = 2.25     # F(2x2,3x3): 16 multiplies per 2x2 outputs and (depth tap, channel) instead of 36
 
 
-def timed(tag: str, flops: float, nbytes: float, fn: Callable[[], None], issued: float = 0.0) -> None:
+def timed(tag: str, flops: float, nbytes: float, fn: Callable[[], None], issued: float = 0.0, valu: float = 0.0) -> None:
     """``flops`` = algorithmic (direct-convolution) count; ``issued`` = flops the kernel puts through the MATRIX pipe
-    (0 for vector-ALU kernels; algorithmic / 2.25 for the Winograd forms)."""
+    (0 for vector-ALU kernels; algorithmic / 2.25 for the Winograd forms); ``valu`` = flops a vector-ALU-bound kernel
+    issues on the packed-fp32 vector pipe (same 157.3 TFLOP/s peak as the fp32 matrix instructions: one pipe)."""
     t = KernelTimer.active
     if t is None:
         fn()
     else:
-        t.launch(tag, flops, nbytes, fn, issued)
+        t.launch(tag, flops, nbytes, fn, issued, valu)

@@ -447,26 +447,31 @@ class Rank1FilterPlan:
         volume._dv_rank1_tables = (self, gl, gr)
         return gl, gr
 
-    def __call__(self, volume: torch.Tensor, noise01: torch.Tensor) -> torch.Tensor:
+    def __call__(self, volume: torch.Tensor, noise01: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``noise01`` None: the unfiltered volume (the origin network's first aggregation layer, acv.py)."""
         p_att = volume._dv_factors[0]
-        noise01 = _dev_f32(noise01, "noise01")
         b, d, h, w = p_att.shape
-        if noise01.numel() != p_att.numel():
-            raise RuntimeError("the filter must be [B,D,H,W]")
         gl, gr = self.tables(volume)
-        s = torch.empty_like(p_att)
         out = torch.empty((b, self.cout, d, h, w), dtype=torch.float32, device=p_att.device)
         lib = _lib.load()
         with torch.cuda.device(p_att.device):
-            _lib.check(lib.dv_mul_f32(p_att.data_ptr(), noise01.data_ptr(), s.data_ptr(), s.numel(), _lib.stream_ptr()),
-                       "dv_mul_f32")
+            if noise01 is None:
+                s = p_att
+            else:
+                noise01 = _dev_f32(noise01, "noise01")
+                if noise01.numel() != p_att.numel():
+                    raise RuntimeError("the filter must be [B,D,H,W]")
+                s = torch.empty_like(p_att)
+                _lib.check(lib.dv_mul_f32(p_att.data_ptr(), noise01.data_ptr(), s.data_ptr(), s.numel(), _lib.stream_ptr()),
+                           "dv_mul_f32")
             # algorithmic flops / bytes of the layer it replaces (SURVEY 8d); issued on the vector ALU, not the matrix pipe
             timed(f"conv3d_k3s1_co{self.cout}_filter_rank1", 2.0 * out.numel() * 2 * self.c * 27,
                   4.0 * (volume.numel() + out.numel() + s.numel()),
                   lambda: _lib.check(lib.dv_conv3d_rank1_filter_f32(s.data_ptr(), gl.data_ptr(), gr.data_ptr(),
                                                                     _lib.ptr(self.scale), _lib.ptr(self.shift),
                                                                     out.data_ptr(), b, d, h, w, self.cout, self.act,
-                                                                    _lib.stream_ptr()), "dv_conv3d_rank1_filter_f32"))
+                                                                    _lib.stream_ptr()), "dv_conv3d_rank1_filter_f32"),
+                  valu=out.numel() * 27 * 3.0)       # per output and tap: one packed add lane + one packed fma lane
         return out
 
 

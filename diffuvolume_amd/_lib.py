@@ -67,6 +67,7 @@ SIGNATURES = {
     "dv_conv2d_wino_packed_floats": (c_size_t, [I, I]),
     "dv_conv2d_wino_pack_weights_f32": (c_int, [P, P, I, I, P]),
     "dv_conv2d_wino_cat_f32": (c_int, [P, P, I, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "dv_conv2d_wino_cat_pair_f32": (c_int, [P, P, I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "dv_conv2d_wino_dil_cat_f32": (c_int, [P, P, I, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "dv_refine_inputs_f32": (c_int, [P, P, P, P, P, P, I, I, I, I, I, P]),
     "dv_softmax_regress_f32": (c_int, [P, P, I, I, I, I, P]),

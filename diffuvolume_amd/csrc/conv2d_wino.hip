@@ -47,6 +47,12 @@ struct Wino2dArgs {
   int ntx, nty, nco;
   int act, fast_ok;
   int dil;                // dilation: the block works on one of the dil*dil sub-sampled images (a dilation-1 problem)
+  // two convolutions that read the same input in one launch (ConvGRU's z and r gates): output channels >= gsplit (a
+  // multiple of 32, 0 = off) belong to the second one, whose result / residual / mul tensors are [B, Cout - gsplit, H, W]
+  int gsplit;
+  const float* residual2;
+  const float* mul2;
+  float* out2;
 };
 
 // DEEP: the low-occupancy variant for launches that do not fill the chip (IGEV's 1/8 and 1/16 scales at batch 1):
@@ -268,13 +274,19 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
   const bool fast = a.fast_ok && dil == 1 && x0 + TW <= a.W && yb + 4 <= a.H;
   const float slope = a.act == DV_ACT_RELU ? 0.f : (a.act == DV_ACT_LEAKY ? 0.01f : 1.f);
   const bool gen = a.act == DV_ACT_MISH || a.act == DV_ACT_SIGMOID || a.act == DV_ACT_TANH;
+  // a block's 32 output channels lie in one group (gsplit % 32 == 0): the group's tensors are chosen per block
+  const bool g2 = a.gsplit > 0 && co0 >= a.gsplit;
+  const int cog0 = g2 ? a.gsplit : 0, coutg = g2 ? a.Cout - a.gsplit : (a.gsplit > 0 ? a.gsplit : a.Cout);
+  float* const outp = g2 ? a.out2 : a.out;
+  const float* const resp = g2 ? a.residual2 : a.residual;
+  const float* const mulp = g2 ? a.mul2 : a.mul;
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int co = co0 + n * 16 + j;
     if (co >= a.Cout) continue;
     const float sc = a.ch_scale ? a.ch_scale[co] : 1.f;
     const float bi = a.ch_bias ? a.ch_bias[co] : 0.f;
-    const size_t cbase = (((size_t)b * a.Cout + co) * a.H + (ry + dil * yb)) * a.W + (rx + dil * xb);
+    const size_t cbase = (((size_t)b * coutg + (co - cog0)) * a.H + (ry + dil * yb)) * a.W + (rx + dil * xb);
 #pragma unroll
     for (int tr = 0; tr < 2; ++tr) {
       float yv[2][4];
@@ -301,27 +313,27 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaf(yv[r][e], sc, bi);
-          if (a.residual) v += *reinterpret_cast<const f32x4*>(a.residual + o);
+          if (resp) v += *reinterpret_cast<const f32x4*>(resp + o);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = gen ? dv_act(v[e], a.act) : fmaxf(v[e], v[e] * slope);
-          if (a.mul) v *= *reinterpret_cast<const f32x4*>(a.mul + o);
+          if (mulp) v *= *reinterpret_cast<const f32x4*>(mulp + o);
           if (a.blend_z) {
             const f32x4 z = *reinterpret_cast<const f32x4*>(a.blend_z + o);
             const f32x4 h = *reinterpret_cast<const f32x4*>(a.blend_h + o);
             v = h + z * (v - h);
           }
-          *reinterpret_cast<f32x4*>(a.out + o) = v;
+          *reinterpret_cast<f32x4*>(outp + o) = v;
         } else if (yb + yr < Hs) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (xb + e < Ws) {
               const size_t oe = o + (size_t)(dil * e);
               float u = fmaf(yv[r][e], sc, bi);
-              if (a.residual) u += a.residual[oe];
+              if (resp) u += resp[oe];
               u = dv_act(u, a.act);
-              if (a.mul) u *= a.mul[oe];
+              if (mulp) u *= mulp[oe];
               if (a.blend_z) u = a.blend_h[oe] + a.blend_z[oe] * (u - a.blend_h[oe]);
-              a.out[oe] = u;
+              outp[oe] = u;
             }
         }
       }
@@ -384,11 +396,39 @@ extern "C" int dv_conv2d_wino_pack_weights_f32(const float* w, float* wpacked, i
   return dv_launch_status();
 }
 
+namespace {
+int wino2d_launch(const float* const* inputs, const int* channels, int n_inputs, const float* wpacked,
+                  const float* ch_scale, const float* ch_bias, const float* residual, const float* mul,
+                  const float* blend_z, const float* blend_h, float* out, int B, int H, int W, int Cout, int dilation,
+                  int act, int gsplit, const float* residual2, const float* mul2, float* out2, dv_stream_t stream);
+}
+
 extern "C" int dv_conv2d_wino_dil_cat_f32(const float* const* inputs, const int* channels, int n_inputs,
                                           const float* wpacked, const float* ch_scale, const float* ch_bias,
                                           const float* residual, const float* mul, const float* blend_z,
                                           const float* blend_h, float* out, int B, int H, int W, int Cout,
                                           int dilation, int act, dv_stream_t stream) {
+  return wino2d_launch(inputs, channels, n_inputs, wpacked, ch_scale, ch_bias, residual, mul, blend_z, blend_h, out, B, H,
+                       W, Cout, dilation, act, 0, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int dv_conv2d_wino_cat_pair_f32(const float* const* inputs, const int* channels, int n_inputs,
+                                           const float* wpacked, const float* ch_scale, const float* ch_bias,
+                                           const float* residual1, const float* mul1, float* out1,
+                                           const float* residual2, const float* mul2, float* out2, int B, int H, int W,
+                                           int Cout1, int Cout2, int act, dv_stream_t stream) {
+  DV_REQUIRE_PTR(out2);
+  DV_REQUIRE(Cout1 > 0 && Cout2 > 0 && Cout1 % 32 == 0, DV_ERR_SHAPE);
+  DV_REQUIRE((!residual2 || dv_aligned16(residual2)) && (!mul2 || dv_aligned16(mul2)) && dv_aligned16(out2), DV_ERR_ALIGN);
+  return wino2d_launch(inputs, channels, n_inputs, wpacked, ch_scale, ch_bias, residual1, mul1, nullptr, nullptr, out1, B,
+                       H, W, Cout1 + Cout2, 1, act, Cout1, residual2, mul2, out2, stream);
+}
+
+namespace {
+int wino2d_launch(const float* const* inputs, const int* channels, int n_inputs, const float* wpacked,
+                  const float* ch_scale, const float* ch_bias, const float* residual, const float* mul,
+                  const float* blend_z, const float* blend_h, float* out, int B, int H, int W, int Cout, int dilation,
+                  int act, int gsplit, const float* residual2, const float* mul2, float* out2, dv_stream_t stream) {
   DV_REQUIRE_PTR(inputs);
   DV_REQUIRE(dilation >= 1 && dilation <= 16, DV_ERR_UNSUPPORTED);
   DV_REQUIRE_PTR(channels);
@@ -419,6 +459,7 @@ extern "C" int dv_conv2d_wino_dil_cat_f32(const float* const* inputs, const int*
   a.fast_ok = (W % 4 == 0) && dv_aligned16(out) && (!residual || dv_aligned16(residual)) &&
               (!mul || dv_aligned16(mul)) && (!blend_z || (dv_aligned16(blend_z) && dv_aligned16(blend_h)));
   a.dil = dilation;
+  a.gsplit = gsplit; a.residual2 = residual2; a.mul2 = mul2; a.out2 = out2;
   a.ntx = cdiv2(cdiv2(W, dilation), w2::TW); a.nty = cdiv2(cdiv2(H, dilation), w2::TH); a.nco = cdiv2(Cout, 32);
   const long long blocks = (long long)B * a.nco * a.nty * a.ntx * dilation * dilation;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return DV_ERR_SHAPE;
@@ -429,6 +470,7 @@ extern "C" int dv_conv2d_wino_dil_cat_f32(const float* const* inputs, const int*
     hipLaunchKernelGGL(conv2d_wino_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   return dv_launch_status();
 }
+}  // namespace
 
 extern "C" int dv_conv2d_wino_cat_f32(const float* const* inputs, const int* channels, int n_inputs,
                                       const float* wpacked, const float* ch_scale, const float* ch_bias,

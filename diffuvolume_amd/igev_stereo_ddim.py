@@ -90,6 +90,11 @@ class IGEVDiffusionLoop:
         if flow_init is not None:
             coords1 = coords1 + flow_init
         flow_up = None
+        # mask_feat_4 is read only after the last iteration (:255-259): this build's update block can skip it elsewhere.
+        # (Measured and not kept: lookup + motion encoder on a second stream beside gru16 / gru08 -- 3.5 % slower at
+        # batch 4, the co-running kernels and the two cross-stream joins per iteration cost more than the idle CUs.)
+        from .update import BasicMultiUpdateBlock
+        skip_mask = isinstance(self.update_block, BasicMultiUpdateBlock)
         for itr in range(iters):
             flow = coords1 - coords0
             corr = corr_fn(flow, coords1, n01f)
@@ -100,7 +105,8 @@ class IGEVDiffusionLoop:
                                              iter08=False, update=False)
             net_list, up_mask, delta_flow = self.update_block(net_list, inp_list, corr, flow,
                                                               iter16=self.n_gru_layers == 3,
-                                                              iter08=self.n_gru_layers >= 2)
+                                                              iter08=self.n_gru_layers >= 2,
+                                                              **({"mask": itr == iters - 1} if skip_mask else {}))
             coords1 = coords1 + delta_flow
             if itr == iters - 1:
                 flow_up = self.upsample_disp(coords1 - coords0, up_mask, stem_2x)[:, :1]

@@ -475,6 +475,70 @@ class Rank1FilterPlan:
         return out
 
 
+class Conv2dPairPlan:
+    """Two biased 3x3 convolutions of the same input in one Winograd launch (ConvGRU's `convz` / `convr`,
+    KITTI15/core/update.py:33-35): out_g = act(conv_g(x) + bias_g + residual_g) [* mul_g].  Launches too small for the
+    Winograd kernel go through the two single plans."""
+
+    def __init__(self, conv1: Tuple[torch.Tensor, Optional[torch.Tensor]], conv2: Tuple[torch.Tensor, Optional[torch.Tensor]],
+                 act: int = ACT_NONE):
+        (w1, b1), (w2, b2) = conv1, conv2
+        self.single = (Conv2dPlan(w1, None, act=act, bias=b1), Conv2dPlan(w2, None, act=act, bias=b2))
+        p1, p2 = self.single
+        self.act, self.cin, self.c1, self.c2 = act, p1.cin, p1.cout, p2.cout
+        self.packed = None
+        if p1.wino_packed is not None and p2.wino_packed is not None and p1.cin == p2.cin and self.c1 % 32 == 0:
+            w = torch.cat([_dev_f32(w1.detach(), "weight"), _dev_f32(w2.detach(), "weight")], dim=0).contiguous()
+            lib = _lib.load()
+            self.packed = torch.empty(lib.dv_conv2d_wino_packed_floats(self.cin, self.c1 + self.c2), dtype=torch.float32,
+                                      device=w.device)
+            with torch.cuda.device(w.device):
+                _lib.check(lib.dv_conv2d_wino_pack_weights_f32(w.data_ptr(), self.packed.data_ptr(), self.cin,
+                                                               self.c1 + self.c2, _lib.stream_ptr()), "conv2d wino weight packing")
+
+            def both(a, b, fill):
+                if a is None and b is None:
+                    return None
+                mk = lambda t, c: t if t is not None else torch.full((c,), fill, dtype=torch.float32, device=w.device)
+                return torch.cat([mk(a, self.c1), mk(b, self.c2)]).contiguous()
+            self.scale, self.shift = both(p1.scale, p2.scale, 1.0), both(p1.shift, p2.shift, 0.0)
+
+    def __call__(self, x, residual=(None, None), mul=(None, None)):
+        parts = [_dev_f32(t, "x") for t in (x if isinstance(x, (list, tuple)) else [x])]
+        b, _, h, w = parts[0].shape
+        blocks = b * (-(-h // 16)) * (-(-w // 16)) * ((self.c1 + self.c2) // 32)
+        if self.packed is None or blocks < Conv2dPlan.WINO_MIN_BLOCKS or not 1 <= len(parts) <= 4:
+            return (self.single[0](x, residual=residual[0], mul=mul[0]), self.single[1](x, residual=residual[1], mul=mul[1]))
+        if sum(t.shape[1] for t in parts) != self.cin or any(t.shape[0] != b or t.shape[2:] != parts[0].shape[2:] for t in parts):
+            raise RuntimeError("virtual concatenation: tensors with equal batch and spatial size, channels summing to Cin")
+        import ctypes
+        outs = [torch.empty((b, c, h, w), dtype=torch.float32, device=parts[0].device) for c in (self.c1, self.c2)]
+
+        def same(t, o, name):
+            if t is None:
+                return None
+            t = _dev_f32(t, name)
+            if tuple(t.shape) != tuple(o.shape):
+                raise RuntimeError(f"{name} shape mismatch")
+            return t
+        res = [same(residual[g], outs[g], "residual") for g in (0, 1)]
+        mu = [same(mul[g], outs[g], "mul") for g in (0, 1)]
+        ptrs = (ctypes.c_void_p * len(parts))(*[t.data_ptr() for t in parts])
+        chans = (ctypes.c_int * len(parts))(*[t.shape[1] for t in parts])
+        lib = _lib.load()
+        n_out = outs[0].numel() + outs[1].numel()
+        extra = sum(t.numel() for t in res + mu if t is not None)
+        with torch.cuda.device(parts[0].device):
+            timed(f"conv2d_k3d1_co{self.c1}+{self.c2}", 2.0 * n_out * self.cin * 9, 4.0 * (sum(t.numel() for t in parts) + n_out + extra),
+                  lambda: _lib.check(lib.dv_conv2d_wino_cat_pair_f32(ptrs, chans, len(parts), self.packed.data_ptr(),
+                                                                     _lib.ptr(self.scale), _lib.ptr(self.shift),
+                                                                     _lib.ptr(res[0]), _lib.ptr(mu[0]), outs[0].data_ptr(),
+                                                                     _lib.ptr(res[1]), _lib.ptr(mu[1]), outs[1].data_ptr(),
+                                                                     b, h, w, self.c1, self.c2, self.act, _lib.stream_ptr()),
+                                     "dv_conv2d_wino_cat_pair_f32"), issued=2.0 * n_out * self.cin * 9 / WINO_MULT_REDUCTION)
+        return outs[0], outs[1]
+
+
 class Conv2dPlan:
     """Conv2d(k 3 or 1, stride 1, padding = dilation) [+ bias] [+ BatchNorm2d eval] [+ residual] [+ activation]
     [+ ConvGRU gate arithmetic] on the 2-D implicit-GEMM kernel: `convbn` / `BasicBlock` of the KITTI12 refinement

@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib
-from .submodule import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, Conv2dPlan
+from .submodule import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, Conv2dPairPlan, Conv2dPlan
 
 
 class _Planned(nn.Module):
@@ -77,15 +77,17 @@ class ConvGRU(_Planned):
         self.convq = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=kernel_size // 2)
 
     def _build(self):
-        return _plan(self.convz, ACT_SIGMOID), _plan(self.convr, ACT_SIGMOID), _plan(self.convq, ACT_TANH)
+        # convz and convr read the same [h | x]: one launch with 2 * hidden output channels
+        return (Conv2dPairPlan((self.convz.weight, self.convz.bias), (self.convr.weight, self.convr.bias), ACT_SIGMOID),
+                _plan(self.convq, ACT_TANH))
 
     def forward(self, h, cz, cr, cq, *x_list):
-        pz, pr, pq = self.plans()
+        pzr, pq = self.plans()
         if len(x_list) > 3:                             # the kernel takes four sources: [h | x1 | x2 | x3]
             x_list = (torch.cat(x_list[:-2], dim=1),) + tuple(x_list[-2:])
         hx = [h, *x_list]                               # torch.cat([h, x]) is never materialised
-        z = pz(hx, residual=cz)                         # sigmoid(convz(hx) + cz)
-        rh = pr(hx, residual=cr, mul=h)                 # sigmoid(convr(hx) + cr) * h
+        # z = sigmoid(convz(hx) + cz),  rh = sigmoid(convr(hx) + cr) * h
+        z, rh = pzr(hx, residual=(cz, cr), mul=(None, h))
         return pq([rh, *x_list], residual=cq, blend=(z, h))                 # (1-z)*h + z*tanh(convq(.) + cq)
 
 
@@ -185,7 +187,10 @@ class BasicMultiUpdateBlock(_Planned):
     def _build(self):
         return _plan(self.mask_feat_4[0], ACT_RELU)
 
-    def forward(self, net, inp, corr=None, disp=None, iter04=True, iter08=True, iter16=True, update=True):
+    def forward(self, net, inp, corr=None, disp=None, iter04=True, iter08=True, iter16=True, update=True,
+                mask=True):
+        """The reference's call (update.py:119-142) plus `mask=False` to skip `mask_feat_4`, which the reference computes
+        in every iteration and reads only after the last one (igev_stereo_ddim.py:255-259)."""
         if self.training:
             raise NotImplementedError("the MI355X update block is inference-only (model.eval())")
         with torch.no_grad():
@@ -205,5 +210,5 @@ class BasicMultiUpdateBlock(_Planned):
             if not update:
                 return net
             delta_disp = self.disp_head(net[0])
-            mask_feat_4 = self.plans()(net[0])
+            mask_feat_4 = self.plans()(net[0]) if mask else None
         return net, mask_feat_4, delta_disp

@@ -205,6 +205,14 @@ int dv_conv2d_wino_cat_f32(const float* const* inputs, const int* channels, int 
                            const float* ch_scale, const float* ch_bias, const float* residual, const float* mul,
                            const float* blend_z, const float* blend_h, float* out, int B, int H, int W, int Cout,
                            int act, dv_stream_t stream);
+/* Two 3x3 convolutions of the SAME input in one launch: ConvGRU's z and r gates (KITTI15/core/update.py:33-35,
+ * `convz(hx)` and `convr(hx)`).  `wpacked` / `ch_scale` / `ch_bias` hold the Cout1 + Cout2 output channels back to back
+ * (pack the concatenated weight; Cout1 % 32 == 0); channels < Cout1 go to out1 [B,Cout1,H,W] with residual1 / mul1,
+ * the others to out2 [B,Cout2,H,W] with residual2 / mul2:  out_g = act(conv_g * scale + bias + residual_g) * mul_g. */
+int dv_conv2d_wino_cat_pair_f32(const float* const* inputs, const int* channels, int n_inputs, const float* wpacked,
+                                const float* ch_scale, const float* ch_bias, const float* residual1, const float* mul1,
+                                float* out1, const float* residual2, const float* mul2, float* out2, int B, int H,
+                                int W, int Cout1, int Cout2, int act, dv_stream_t stream);
 /* The same with dilation 1..16 (the refinement network's dilated layers, KITTI12/models/submodule.py:251-306, and the
  * dilated blocks of the 2-D feature CNNs): a dilation-d 3x3 convolution is d*d independent dilation-1 convolutions on the
  * sub-sampled images, so each block runs the Winograd kernel on a 16x16 tile of one sub-image.  Same packed weights. */

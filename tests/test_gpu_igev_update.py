@@ -257,3 +257,26 @@ def test_conv2d_ksplit_small_launches(cfg):
     out = plan(*args, **kw)
     assert float((out.cpu() - y).abs().max() / y.abs().max()) < 1e-5
     assert torch.equal(plan(*args, **kw), out)
+
+
+@pytest.mark.parametrize("shape", [(2, 40, 72), (1, 96, 312), (3, 23, 50)])
+def test_gru_gate_pair_launch_equals_the_two_convolutions(shape):
+    """ConvGRU's convz / convr (update.py:33-35) read the same [h | x]: Conv2dPairPlan runs them as one Winograd launch.
+    Every output element is computed by the same instruction sequence as in a single Winograd launch: bit-equal."""
+    b, h, w = shape
+    g = _gen(31, "gate_pair")
+    parts = [dev(torch.randn(b, c, h, w, generator=g)) for c in (128, 127, 1, 128)]
+    w1, w2 = (dev(torch.randn(128, 384, 3, 3, generator=g) * 0.03) for _ in range(2))
+    b1, b2 = (dev(torch.randn(128, generator=g) * 0.1) for _ in range(2))
+    cz, cr = (dev(torch.randn(b, 128, h, w, generator=g)) for _ in range(2))
+    pair = S.Conv2dPairPlan((w1, b1), (w2, b2), S.ACT_SIGMOID)
+    z, rh = pair(parts, residual=(cz, cr), mul=(None, parts[0]))
+    z1 = S.Conv2dPlan(w1, None, act=S.ACT_SIGMOID, bias=b1)(parts, residual=cz)
+    rh1 = S.Conv2dPlan(w2, None, act=S.ACT_SIGMOID, bias=b2)(parts, residual=cr, mul=parts[0])
+    if b * -(-h // 16) * -(-w // 16) * 4 >= S.Conv2dPlan.WINO_MIN_BLOCKS:        # the single launches are Winograd too
+        assert torch.equal(z, z1) and torch.equal(rh, rh1)
+    else:                                                                        # they ran the direct / K-split kernel
+        assert rel_err(z, z1.cpu()) < 1e-5 and rel_err(rh, rh1.cpu()) < 1e-5
+    ref = torch.sigmoid(F.conv2d(torch.cat(parts, 1).double().cpu(), w2.double().cpu(), b2.double().cpu(), padding=1)
+                        + cr.double().cpu()) * parts[0].double().cpu()
+    assert rel_err(rh, ref) < 1e-5

@@ -23,7 +23,7 @@ LAYERS = {  # name: (kind, cin, cout, k, stride, (D,H,W))
     "k1_64": ("conv", 64, 64, 1, 1, (24, 64, 120)),
 }
 names = sys.argv[1:] or list(LAYERS)
-iters = 5
+iters = 20
 dev = "cuda:0"
 for n in names:
     kind, cin, cout, k, s, dims = LAYERS[n]

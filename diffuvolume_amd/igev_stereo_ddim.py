@@ -23,7 +23,7 @@ from torch import nn
 from . import _lib
 from .acv_ddim import cosine_beta_schedule
 from .head import SinusoidalPositionEmbeddings
-from .submodule import (ACT_LEAKY, ACT_NONE, Conv3dPlan, Deconv3dPlan, _dev_f32, build_gwc_volume,
+from .submodule import (ACT_LEAKY, ACT_NONE, Conv2dPlan, Conv3dPlan, Deconv2dK4S2Plan, Deconv3dPlan, _dev_f32, build_gwc_volume,
                         feature_gate, softmax_regress)
 
 
@@ -640,6 +640,7 @@ class IGEVStereo_ddim(nn.Module):
         self.cost_agg = hourglass(8)
         self.classifier = nn.Conv3d(8, 1, 3, 1, 1, bias=False)
         self._plans = None
+        self._spx = None
 
     # ---- plan cache (same rules as the other wrappers) ----------------------------------------------
     def _apply(self, fn, *a, **k):
@@ -660,6 +661,20 @@ class IGEVStereo_ddim(nn.Module):
             self._plans = (self.corr_stem.plan(), Conv3dPlan(self.classifier.weight, None, stride=1, act=ACT_NONE))
         return self._plans
 
+    def _spx_plans(self):
+        """`spx_2_gru` (transposed conv + BN + LeakyReLU, concat with the 1/2-resolution stem, 3x3 conv + BN + LeakyReLU)
+        and `spx_gru` (biased transposed conv to the 9 convex-upsampling logits) as HIP plans."""
+        c1, c2, head = self.spx_2_gru.conv1, self.spx_2_gru.conv2, self.spx_gru[0]
+        bn = lambda m: (m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var) if m.use_bn else ()
+        tensors = (c1.conv.weight, *bn(c1), c2.conv.weight, *bn(c2), head.weight, head.bias)
+        key = tuple((t.data_ptr(), t._version) for t in tensors)        # children loaded / moved / overwritten in place
+        if self._spx is None or self._spx[0] != key:
+            act = lambda m: ACT_LEAKY if m.relu else ACT_NONE
+            self._spx = (key, (Deconv2dK4S2Plan(c1.conv.weight, bn(c1) or None, act=act(c1), eps=c1.bn.eps),
+                               Conv2dPlan(c2.conv.weight, bn(c2) or None, act=act(c2), eps=c2.bn.eps),
+                               Deconv2dK4S2Plan(head.weight, None, bias=head.bias)))
+        return self._spx[1]
+
     def freeze_bn(self):
         for m in self.modules():
             if isinstance(m, nn.BatchNorm2d):
@@ -667,9 +682,16 @@ class IGEVStereo_ddim(nn.Module):
 
     # ---- pieces -----------------------------------------------------------------------------------------
     def upsample_disp(self, disp, mask_feat_4, stem_2x):
-        """:209-217: spx_2_gru / spx_gru (2-D, PyTorch), then softmax over the 9 taps + context_upsample(disp*4)
-        in one HIP pass.  Returns [B,1,4h,4w]."""
-        spx_pred = self.spx_gru(self.spx_2_gru(mask_feat_4, stem_2x))
+        """:209-217: spx_2_gru / spx_gru (3x3 HIP kernels; the transposed convolutions as four parity convolutions + pixel
+        shuffle), then softmax over the 9 taps + context_upsample(disp*4) in one HIP pass.  Returns [B,1,4h,4w]."""
+        if mask_feat_4.is_cuda and self.spx_2_gru.concat:
+            up, mix, head = self._spx_plans()
+            x = up(mask_feat_4)
+            if x.shape != stem_2x.shape:
+                x = F.interpolate(x, size=(stem_2x.shape[-2], stem_2x.shape[-1]), mode="nearest")
+            spx_pred = head(mix([x, stem_2x]))              # torch.cat((x, rem), 1) is never materialised
+        else:
+            spx_pred = self.spx_gru(self.spx_2_gru(mask_feat_4, stem_2x))
         return context_upsample(disp, spx_pred, scale=4.0, apply_softmax=True).unsqueeze(1)
 
     def cost_volume(self, match_left, match_right, features_left):

@@ -475,6 +475,34 @@ class Rank1FilterPlan:
         return out
 
 
+class Deconv2dK4S2Plan:
+    """ConvTranspose2d(kernel 4, stride 2, padding 1) [+ bias] [+ BatchNorm2d eval] [+ activation] -- IGEV's `spx_2_gru.conv1`
+    and `spx_gru` (KITTI15/core/igev_stereo_ddim.py:110-112, core/submodule.py:27-28) -- on the 3x3 kernels: output pixel
+    (2i+a, 2j+b) reads the 2x2 inputs {i-1+a, i+a} x {j-1+b, j+b}, so the four output parities are four 3x3 stride-1
+    convolutions of the input (each with five structurally zero taps) whose results interleave (pixel shuffle)."""
+
+    def __init__(self, weight: torch.Tensor, bn=None, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+                 eps: float = 1e-5):
+        w = _dev_f32(weight.detach(), "weight")                  # [Cin, Cout, 4, 4]
+        if tuple(w.shape[2:]) != (4, 4):
+            raise _lib.DiffuVolumeError("Deconv2dK4S2Plan: kernel 4, stride 2, padding 1")
+        cin, cout = w.shape[0], w.shape[1]
+        self.cout = cout
+        wc = torch.zeros((cout, 2, 2, cin, 3, 3), dtype=torch.float32, device=w.device)
+        tap = {0: {0: 1, -1: 3}, 1: {1: 0, 0: 2}}              # parity -> {input offset: kernel index}
+        for a in (0, 1):
+            for dy, ky in tap[a].items():
+                for b in (0, 1):
+                    for dx, kx in tap[b].items():
+                        wc[:, a, b, :, dy + 1, dx + 1] = w[:, :, ky, kx].t()
+        rep = lambda t: None if t is None else t.detach().repeat_interleave(4)
+        self.conv = Conv2dPlan(wc.reshape(cout * 4, cin, 3, 3), None if bn is None else tuple(rep(t) for t in bn), act=act,
+                               eps=eps, bias=rep(bias))
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        return torch.nn.functional.pixel_shuffle(self.conv(x), 2)
+
+
 class Conv2dPairPlan:
     """Two biased 3x3 convolutions of the same input in one Winograd launch (ConvGRU's `convz` / `convr`,
     KITTI15/core/update.py:33-35): out_g = act(conv_g(x) + bias_g + residual_g) [* mul_g].  Launches too small for the

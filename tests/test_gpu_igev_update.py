@@ -280,3 +280,26 @@ def test_gru_gate_pair_launch_equals_the_two_convolutions(shape):
     ref = torch.sigmoid(F.conv2d(torch.cat(parts, 1).double().cpu(), w2.double().cpu(), b2.double().cpu(), padding=1)
                         + cr.double().cpu()) * parts[0].double().cpu()
     assert rel_err(rh, ref) < 1e-5
+
+
+@pytest.mark.parametrize("cfg", [(2, 32, 32, 24, 78, True), (1, 64, 9, 48, 156, False), (2, 12, 5, 7, 9, False)])
+def test_deconv2d_k4s2_as_parity_convolutions(cfg):
+    """ConvTranspose2d(k 4, s 2, p 1) [+ BN + LeakyReLU | + bias] of IGEV's spx heads (igev_stereo_ddim.py:110-112,
+    :209-217) on the 3x3 kernels + pixel shuffle, against PyTorch's own transposed convolution in float64."""
+    b, cin, cout, h, w, with_bn = cfg
+    g = _gen(57, "deconv2d")
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cin, cout, 4, 4, generator=g) * 0.1
+    if with_bn:
+        bn = (torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1,
+              torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5)
+        ref = F.conv_transpose2d(x.double(), wt.double(), None, 2, 1)
+        ref = F.leaky_relu(F.batch_norm(ref, bn[2].double(), bn[3].double(), bn[0].double(), bn[1].double(), False, 0.0, 1e-5), 0.01)
+        plan = S.Deconv2dK4S2Plan(dev(wt), tuple(dev(t) for t in bn), act=S.ACT_LEAKY)
+    else:
+        bias = torch.randn(cout, generator=g) * 0.1
+        ref = F.conv_transpose2d(x.double(), wt.double(), bias.double(), 2, 1)
+        plan = S.Deconv2dK4S2Plan(dev(wt), None, bias=dev(bias))
+    out = plan(dev(x))
+    assert tuple(out.shape) == (b, cout, 2 * h, 2 * w)
+    assert rel_err(out, ref) < 1e-5

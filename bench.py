@@ -550,15 +550,15 @@ def main():
         # the first layer of every step on the factors of its input (csrc/rank1_filter.hip): vector-ALU / LDS bound
         r1 = ks.get("conv3d_k3s1_co32_filter_rank1")
         if r1:
-            side.append({"kernel": "rank1_filter_conv_kernel<2>", "tags": ["conv3d_k3s1_co32_filter_rank1"], "bound": "valu",
+            side.append({"kernel": "rank1_filter_split_kernel", "tags": ["conv3d_k3s1_co32_filter_rank1"], "bound": "valu",
                          "launches": r1["launches"], "avg_ms": r1["total_ms"] / r1["launches"],
                          "ms_per_step": r1["total_ms"] / a.steps, "achieved": r1["valu_flops"] / r1["total_ms"] / 1e9,
                          "unit": "TFLOP/s", "peak": PEAK_MFMA_F32_TFLOPS, "frac": r1["valu_flops"] / r1["total_ms"] / 1e9 / PEAK_MFMA_F32_TFLOPS,
                          "algorithmic_tflops": r1["flops"] / r1["total_ms"] / 1e9,
-                         "note": "dres0[0] of acv_ddim.py:200-203 on s * [L ; R(x-d)]: 81 vector flops per output instead of "
+                         "note": "dres0[0] of acv_ddim.py:200-203 on s * [L ; R(x-d)]: 108 vector flops per output instead of "
                                  "3456 matrix flops; algorithmic_tflops counts the layer it replaces (SURVEY 8d), peak = "
                                  "packed-fp32 vector rate (the same pipe as the fp32 MFMA)",
-                         "traffic": pmc_traffic("rank1_filter_conv_kernel<2>")})
+                         "traffic": pmc_traffic("rank1_filter_split_kernel")})
         out["roofline_kernels"] = side
         # whole path against the matrix pipe: flops the kernels ISSUE (Winograd layers: algorithmic / 2.25; vector-ALU
         # kernels: 0) over the wall time of the `value` pass

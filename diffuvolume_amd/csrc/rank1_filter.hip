@@ -17,13 +17,9 @@
 // 27 * 2C -- 32x fewer for C = 32 -- and reads a [B,D,H,W] scalar field instead of the 3 GB volume.  It is the exact
 // same function (validated to 9e-15 in float64); in fp32 it is a re-association of the sums like any other tiling.
 // The reference's layer is 163 of the 751 GFLOP of a step; here it is bound by the vector ALU (108 flop
-// per output) and by LDS reads of GR.
-//
-// Kernel: a block = one image row y of one (batch item, group of 4 output channels), all disparities.  Thread = one
-// x; it keeps its 27 x 4 GL values in registers (they do not depend on d) and the 3 x 3 x 3 neighbourhood of s as a
-// rolling window over d (9 loads per step).  GR depends on x - d: the three source rows of every tap sit in LDS as
-// [tap][u][4 co] (16 bytes per u: one conflict-free ds_read_b128 per tap and step, consecutive lanes read consecutive
-// slots), zero for u < 0.  BN scale / bias and the activation are applied before the store, as in the conv kernels.
+// per output).  BN scale / bias and the activation are applied before the store, as in the conv kernels.
+
+#include <type_traits>
 
 #include "dv_common.h"
 
@@ -31,16 +27,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <int N> struct VecOf;
-template <> struct VecOf<4> { typedef f32x4 type; };
-template <> struct VecOf<2> { typedef f32x2 type; };
-
-constexpr int R1_XT = 256;       // x positions per block (one per thread)
 constexpr int R1_DMAX = 48;      // disparities of a quarter-resolution volume (maxdisp 192: hard-coded in the reference)
-#ifndef R1_CPT
-#define R1_CPT 2
-#endif
-constexpr int R1_UW = R1_XT + R1_DMAX + 3;   // LDS slots per tap: u = x - d + (tx - td) over a block's x and all d
 
 struct Rank1Args {
   const float* s;        // [B, D, H, W]      p * n01
@@ -50,209 +37,268 @@ struct Rank1Args {
   const float* ch_bias;  // [Cout] or null
   float* out;            // [B, Cout, D, H, W]
   int B, D, H, W, Cout;
-  int ntx, ncg;          // x tiles per row, groups of CPT output channels
+  int ntx, ncg;          // x tiles per row, pairs of output channels
   int act;
 };
 
-// CPT = output channels per thread (and per block): 4 -> 130 KB of LDS, one block (one wave per SIMD) per CU;
-// 2 -> 65 KB, two blocks per CU and half the registers per thread
-template <int CPT>
-__global__ __launch_bounds__(R1_XT, CPT == 4 ? 1 : 2) void rank1_filter_conv_kernel(Rank1Args a) {
-  typedef typename VecOf<CPT>::type vec;
-  constexpr int UW = R1_UW;
-  __shared__ __attribute__((aligned(16))) float gr_s[27 * R1_UW * CPT];   // [27][UW][CPT co]
-  const int tid = threadIdx.x;
+// ---- the kernel ---------------------------------------------------------------------------------------------------------
+// The GL term wants a thread that keeps x fixed while it walks d (GL[tap](y', x') is then constant: registers); the GR
+// term wants a thread that keeps u = x - d fixed (GR[tap](y', x' - d') = GR[tap](y', u + tx - td) is then constant too).
+// So a block = one image row of one pair of output channels runs both walks side by side: waves 0-3 ("diagonal") own
+// one u each and step along (d, x = u + d), waves 4-7 ("straight") own one x each; both keep their 27 x 2 table values
+// in registers and issue 27 packed fmas per step.  What they read in the loop is s only, and they read it from LDS: the
+// block stages the three rows of six planes at a time (one barrier per six steps; global loads whose range check is
+// the zero padding, issued a round ahead), a step consumes ONE plane -- its nine positions feed output e + 1 through
+// the td = 0 taps, output e through td = 1 and output e - 1 through td = 2 (three rotating accumulators) -- so nothing
+// but the current plane's 15 / 9 values is ever held.  The diagonal waves leave their finished sums in a small LDS ring;
+// the straight waves add theirs a round later, apply BN + the activation and store.
+// History (round 3): a first form kept the GR rows of all 27 taps in LDS ([tap][u][2 co], 65 KB) and walked d with one
+// thread per x: one ds_read_b64 + one packed add per fma, 1.22 ms per launch at B = 8.  This form has a third of the LDS
+// reads and no add: 0.95 ms.  A version of it that read s from global memory in both walks was bound by its vector
+// memory instructions (24 per output step and wave pair, about one per 8 cycles per CU): 1.28 ms.
+constexpr int R1S_G = 6;                       // planes per round (a multiple of the 3-step accumulator rotation)
+constexpr int R1S_COLS = 256;                  // threads per role = ring row stride
+constexpr int R1S_SROW = 272;                  // staged columns x0 - 3 .. x0 + 268
+constexpr int R1S_STAGE = R1S_G * 3 * R1S_SROW;
+constexpr int R1S_NS = (R1S_STAGE + 511) / 512;
+
+template <int HI>
+__device__ __forceinline__ void r1_mac(f32x2& acc, const f32x2& g, const f32x2& sv) {
+  // acc += g * (the HI-th half of sv, broadcast to both channels)
+  if constexpr (HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(g), "v"(sv));
+  else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(g), "v"(sv));
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void rank1_filter_split_kernel(Rank1Args a, int xt) {
+  __shared__ __attribute__((aligned(16))) f32x2 ring[2 * R1S_G * R1S_COLS];      // finished GR sums, slot = d mod 12
+  __shared__ __attribute__((aligned(16))) float s_ring[2 * R1S_STAGE];           // [round & 1][plane 6][row 3][col]
+  const int tid = threadIdx.x & 255;
+  const bool diag = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) == 0;
   unsigned t = blockIdx.x;
-  const int cg = t % a.ncg; t /= a.ncg;      // the channel groups of a row side by side: they share s and the row's lines
+  const int cg = t % a.ncg; t /= a.ncg;
   const int tx = t % a.ntx; t /= a.ntx;
   const int y = t % a.H;
   const int b = t / a.H;
-  const int x0 = tx * R1_XT, x = x0 + tid;
-  const int co0 = cg * CPT;
+  const int x0 = tx * xt;
+  const int xlim = a.W - x0 < xt ? a.W - x0 : xt;          // columns of this tile
+  const int co0 = cg * 2;
+  const int nch = a.Cout - co0 < 2 ? a.Cout - co0 : 2;
   const size_t plane = (size_t)a.H * a.W;
-  const float* glb = a.gl + ((size_t)b * 27 * a.Cout) * plane;
-  const float* grb = a.gr + ((size_t)b * 27 * a.Cout) * plane;
-  const float* sb = a.s + (size_t)b * a.D * plane;
-
-  // ---- GR rows -> LDS: slot ui <-> u = x0 - (D - 1) - 2 + ui; value 0 for u outside [0, W) or y' outside the image.
-  // Buffer loads (descriptor = this batch item's table, lane offset 2^31 where the value is 0 by definition), nine
-  // taps = 18 x CPT independent loads in flight before the first LDS store: the fill is a latency chain otherwise
-  // (one L2 round trip per slot), and it is a fifth of the block's memory instructions.
-  const int umin = x0 - (a.D - 1) - 2;
-  constexpr int NK = (UW + R1_XT - 1) / R1_XT;
-  const int tab_bytes = __builtin_amdgcn_readfirstlane((int)((size_t)27 * a.Cout * plane * sizeof(float)));   // < 2^31 (host check)
   const int plane_b = __builtin_amdgcn_readfirstlane((int)(plane * sizeof(float)));
-  auto table_rsrc = [&](const float* base) __attribute__((always_inline)) {
-    const uint64_t p64 = reinterpret_cast<uint64_t>(base);
-    const uint64_t ps = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p64) |
-                        ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(p64 >> 32)) << 32);
-    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(ps), 0, tab_bytes, 0x00020000);
+  const int row_b = __builtin_amdgcn_readfirstlane(a.W * 4);
+  const int tab_bytes = __builtin_amdgcn_readfirstlane((int)((size_t)27 * a.Cout * plane * sizeof(float)));
+  auto scalar64 = [](const void* p) __attribute__((always_inline)) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    return (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v) |
+           ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32);
   };
-  const auto gr_rs = table_rsrc(grb);
-  int uoff[NK];
+  // steps e = 0 .. D (plane D is all zero and completes output D - 1), in rounds of six
+  const int nrounds = (a.D + 1 + R1S_G - 1) / R1S_G;
+
+  // ---- staging of s: element i of a round = (plane i / (3 SROW), row (i / SROW) % 3, col i % SROW) ----
+  const auto s_rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(scalar64(a.s + (size_t)b * a.D * plane)), 0,
+                                                      a.D * plane_b, 0x00020000);
+  int soff[R1S_NS];
+  float sv[R1S_NS];
 #pragma unroll
-  for (int k = 0; k < NK; ++k) {
-    const int u = umin + tid + k * R1_XT;
-    uoff[k] = (tid + k * R1_XT < UW && (unsigned)u < (unsigned)a.W) ? u * 4 : (int)0x80000000u;
+  for (int i = 0; i < R1S_NS; ++i) {
+    const int idx = (int)threadIdx.x + 512 * i;
+    const int pl = idx / (3 * R1S_SROW), r2 = idx - pl * (3 * R1S_SROW);
+    const int row = r2 / R1S_SROW, col = r2 - row * R1S_SROW;
+    const int yy = y + row - 1, xx = x0 - 3 + col;
+    const bool ok = idx < R1S_STAGE && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+    soff[i] = ok ? pl * plane_b + (yy * a.W + xx) * 4 : (int)0x80000000u;    // + first plane of the round (scalar)
   }
-#pragma unroll 1
-  for (int t9 = 0; t9 < 27; t9 += 9) {
-    float v[9][NK][CPT];
+  auto stage_fetch = [&](int round) __attribute__((always_inline)) {
+    const int so = round * R1S_G * plane_b;                // planes >= D fall off the descriptor: zeros
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      const int tap = t9 + i;
-      const int yy = y + (tap / 3) % 3 - 1;
-      const bool yok = (unsigned)yy < (unsigned)a.H;
-      // scalar part: channel (tap * Cout + co0 + c) and row yy; rows outside the image: the invalid lane offset
-      const int so = yok ? (tap * a.Cout + co0) * plane_b + yy * a.W * 4 : 0;
+    for (int i = 0; i < R1S_NS; ++i) sv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s_rs, soff[i], so, 0));
+  };
+  auto stage_commit = [&](int round) __attribute__((always_inline)) {
+    float* dst = s_ring + (round & 1) * R1S_STAGE;
 #pragma unroll
-      for (int k = 0; k < NK; ++k) {
-        const int vo = yok ? uoff[k] : (int)0x80000000u;
+    for (int i = 0; i < R1S_NS; ++i) {
+      const int idx = (int)threadIdx.x + 512 * i;
+      if (idx < R1S_STAGE) dst[idx] = sv[i];
+    }
+  };
+  stage_fetch(0);
+
+  if (diag) {
+    // ---------------- diagonal walk: u fixed, x = u + d ----------------
+    const int umin = x0 == 0 ? -2 : x0 - (a.D - 1);
+    const int u = umin + tid;
+    const auto gr_rs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<float*>(scalar64(a.gr + ((size_t)b * 27 * a.Cout) * plane)), 0, tab_bytes, 0x00020000);
+    f32x2 gr[27];
+    {
+      int goff[5];                                        // column u + k - 2, k = tx - td + 2
 #pragma unroll
-        for (int c = 0; c < CPT; ++c)
-          v[i][k][c] = (co0 + c < a.Cout)
-                           ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr_rs, vo, so + c * plane_b, 0))
-                           : 0.f;
+      for (int k = 0; k < 5; ++k) goff[k] = (unsigned)(u + k - 2) < (unsigned)a.W ? (u + k - 2) * 4 : (int)0x80000000u;
+#pragma unroll
+      for (int tap = 0; tap < 27; ++tap) {
+        const int td = tap / 9, ty = (tap / 3) % 3, tx3 = tap % 3;
+        const int yy = y + ty - 1;
+        const bool yok = (unsigned)yy < (unsigned)a.H;
+        const int so = yok ? (tap * a.Cout + co0) * plane_b + yy * row_b : 0;
+        const int vo = yok ? goff[tx3 - td + 2] : (int)0x80000000u;
+        f32x2 v = {0.f, 0.f};
+        v[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr_rs, vo, so, 0));
+        if (nch > 1) v[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr_rs, vo, so + plane_b, 0));
+        gr[tap] = v;
       }
     }
+    stage_commit(0);
+    // every table load has landed before the loop: otherwise the first use of a table register inside it carries a
+    // vmcnt(n) computed for the first trip, which on every later trip waits for that round's freshly issued stage loads
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+    __syncthreads();
+    // plane e: this lane reads columns u + e - 2 .. u + e + 2 = staged columns cb .. cb + 4, cb = u + e + 1 - x0.
+    // Lanes whose outputs lie outside the tile read whatever is there (clamped into the row): their sums are dropped.
+    auto step = [&](int e, const float* pl, f32x2& accP, f32x2& accC, f32x2& accN) __attribute__((always_inline)) {
+      int cb = u + e + 1 - x0;
+      cb = cb < 0 ? 0 : (cb > R1S_SROW - 5 ? R1S_SROW - 5 : cb);
+      const float* sp = pl + cb;
+      f32x2 w[3][3];                                       // a row's five values as pairs (k, k + 1): no cross-row packing
 #pragma unroll
-    for (int i = 0; i < 9; ++i)
+      for (int ty = 0; ty < 3; ++ty) {
 #pragma unroll
-      for (int k = 0; k < NK; ++k) {
-        const int ui = tid + k * R1_XT;
-        if (ui < UW) {
-          vec q;
-#pragma unroll
-          for (int c = 0; c < CPT; ++c) q[c] = v[i][k][c];
-          reinterpret_cast<vec*>(gr_s)[(t9 + i) * UW + ui] = q;
-        }
+        for (int k = 0; k < 5; ++k) w[ty][k >> 1][k & 1] = sp[ty * R1S_SROW + k];
       }
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+        for (int tx3 = 0; tx3 < 3; ++tx3) {
+          const int k0 = tx3 + 2, k1 = tx3 + 1, k2 = tx3;                                  // k = tx - td + 2
+          if (k0 & 1) r1_mac<1>(accN, gr[ty * 3 + tx3], w[ty][k0 >> 1]); else r1_mac<0>(accN, gr[ty * 3 + tx3], w[ty][k0 >> 1]);
+          if (k1 & 1) r1_mac<1>(accC, gr[9 + ty * 3 + tx3], w[ty][k1 >> 1]); else r1_mac<0>(accC, gr[9 + ty * 3 + tx3], w[ty][k1 >> 1]);
+          if (k2 & 1) r1_mac<1>(accP, gr[18 + ty * 3 + tx3], w[ty][k2 >> 1]); else r1_mac<0>(accP, gr[18 + ty * 3 + tx3], w[ty][k2 >> 1]);
+        }
+      const int d = e - 1, col = u + d - x0;
+      if (d >= 0 && (unsigned)col < (unsigned)xlim) ring[(d % (2 * R1S_G)) * R1S_COLS + col] = accP;
+      accP = (f32x2){0.f, 0.f};
+    };
+    f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
+#pragma unroll 1
+    for (int r = 0; r < nrounds; ++r) {
+      if (r + 1 < nrounds) stage_fetch(r + 1);
+      const float* base = s_ring + (r & 1) * R1S_STAGE;
+      const int e = r * R1S_G;
+      step(e, base, a0, a1, a2);
+      step(e + 1, base + 3 * R1S_SROW, a1, a2, a0);
+      step(e + 2, base + 6 * R1S_SROW, a2, a0, a1);
+      step(e + 3, base + 9 * R1S_SROW, a0, a1, a2);
+      step(e + 4, base + 12 * R1S_SROW, a1, a2, a0);
+      step(e + 5, base + 15 * R1S_SROW, a2, a0, a1);
+      if (r + 1 < nrounds) stage_commit(r + 1);
+      __syncthreads();
+    }
+    return;
   }
 
-  // ---- GL: 27 x CPT registers, constant over d (branch-free buffer loads like the fill above)
-  const auto gl_rs = table_rsrc(glb);
-  vec gl[27];
+  // ---------------- straight walk: x fixed ----------------
+  const int x = x0 + tid;
+  const bool xin = tid < xlim;
+  const auto gl_rs = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<float*>(scalar64(a.gl + ((size_t)b * 27 * a.Cout) * plane)), 0, tab_bytes, 0x00020000);
+  f32x2 gl[27];
   {
-    int goff[9];
+    int roff[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
       const int yy = y + q / 3 - 1, xx = x + q % 3 - 1;
-      goff[q] = ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) ? (yy * a.W + xx) * 4 : (int)0x80000000u;
+      roff[q] = (xin && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) ? (yy * a.W + xx) * 4 : (int)0x80000000u;
     }
 #pragma unroll
     for (int tap = 0; tap < 27; ++tap) {
       const int so = (tap * a.Cout + co0) * plane_b;
-      vec v = {};
-#pragma unroll
-      for (int c = 0; c < CPT; ++c)
-        if (co0 + c < a.Cout)
-          v[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gl_rs, goff[tap % 9], so + c * plane_b, 0));
+      f32x2 v = {0.f, 0.f};
+      v[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gl_rs, roff[tap % 9], so, 0));
+      if (nch > 1) v[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gl_rs, roff[tap % 9], so + plane_b, 0));
       gl[tap] = v;
     }
   }
-
-  // ---- rolling 3 x 3 x 3 window of s: plane p of the window = s(d + p - 1, y + ty - 1, x + tx - 1), q = ty*3 + tx.
-  // Buffer loads: one descriptor per batch item, a constant 32-bit lane offset per neighbour (2^31 outside the image:
-  // the range check returns 0), the plane as a scalar offset; planes outside [0, D) get a zero-record descriptor.
-  // No branch, no 64-bit vector arithmetic in the loop (one wave per SIMD: nothing would hide them).
-  int roff[9];
+  float sc[2] = {1.f, 1.f}, bi[2] = {0.f, 0.f};
 #pragma unroll
-  for (int q = 0; q < 9; ++q) {
-    const int yy = y + q / 3 - 1, xx = x + q % 3 - 1;
-    roff[q] = ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) ? (yy * a.W + xx) * 4 : (int)0x80000000u;
-  }
-  const int plane_bytes = __builtin_amdgcn_readfirstlane((int)(plane * sizeof(float)));
-  const uint64_t sp64 = reinterpret_cast<uint64_t>(sb);
-  const uint64_t sps = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sp64) |
-                       ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sp64 >> 32)) << 32);
-  auto load_plane = [&](int d, f32x2* dst) __attribute__((always_inline)) {
-    const bool dok = (unsigned)d < (unsigned)a.D;
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(sps), 0, dok ? a.D * plane_bytes : 0, 0x00020000);
-    const int so = dok ? d * plane_bytes : 0;
-#pragma unroll
-    for (int q = 0; q < 9; ++q) dst[q][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, roff[q], so, 0));
-  };
-  // (a window value lives in the low half of a register pair: the packed fma below broadcasts it to both channels
-  // through op_sel instead of a move per tap)
-  f32x2 sw[3][9];
-#pragma unroll
-  for (int p3 = 0; p3 < 3; ++p3)
-#pragma unroll
-    for (int q = 0; q < 9; ++q) sw[p3][q] = (f32x2){0.f, 0.f};       // plane -1 stays zero
-  load_plane(0, sw[1]);
-  load_plane(1, sw[2]);
-
-  float sc[CPT], bi[CPT];
-#pragma unroll
-  for (int c = 0; c < CPT; ++c) {
-    sc[c] = 1.f;
-    bi[c] = 0.f;
-  }
-#pragma unroll
-  for (int c = 0; c < CPT; ++c)
-    if (co0 + c < a.Cout) {
+  for (int c = 0; c < 2; ++c)
+    if (c < nch) {
       if (a.ch_scale) sc[c] = a.ch_scale[co0 + c];
       if (a.ch_bias) bi[c] = a.ch_bias[co0 + c];
     }
-  __syncthreads();
-
-  // output: one descriptor over the 4 channel volumes of this block, lane offset (y*W + x)*4 (2^31 for x >= W: the
-  // store is dropped), channel and plane as a scalar offset
   const size_t vol = (size_t)a.D * plane;
   const int vol_bytes = __builtin_amdgcn_readfirstlane((int)(vol * sizeof(float)));
-  const int nch = a.Cout - co0 < CPT ? a.Cout - co0 : CPT;
-  const uint64_t op64 = reinterpret_cast<uint64_t>(a.out + ((size_t)b * a.Cout + co0) * vol);
-  const uint64_t ops = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)op64) |
-                       ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(op64 >> 32)) << 32);
-  const auto ors = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(ops), 0, nch * vol_bytes, 0x00020000);
-  const int ooff = x < a.W ? (y * a.W + x) * 4 : (int)0x80000000u;
+  const auto ors = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<float*>(scalar64(a.out + ((size_t)b * a.Cout + co0) * vol)), 0, nch * vol_bytes, 0x00020000);
+  const int ooff = xin ? (y * a.W + x) * 4 : (int)0x80000000u;
   const float slope = a.act == DV_ACT_RELU ? 0.f : (a.act == DV_ACT_LEAKY ? 0.01f : 1.f);
   const bool mish = a.act == DV_ACT_MISH;
-  // LDS slot of tap (td, ., tx) at step d for this lane: u = x - d + (tx - td)  ->  ui = tid + (D - 1) + 2 - d + tx - td
-  const vec* grq = reinterpret_cast<const vec*>(gr_s) + tid + (a.D - 1) + 2;
-  // one step: planes (pa, pb, pc) of the window are (d - 1, d, d + 1); plane d + 2 is requested into pa's registers
-  // once they have been read (three steps per trip: the window rotates through its three register sets, no moves)
-  auto mac = [&](vec& acc, const f32x2& sv, const vec& g) __attribute__((always_inline)) {
-    if constexpr (CPT == 2) {
-      asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(g), "v"(sv));
-    } else {
-      acc += sv[0] * g;
+  stage_commit(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): as in the diagonal walk
+  __syncthreads();
+  // plane e: columns x - 1 .. x + 1 = staged columns tid + 2 .. tid + 4
+  f32x2 done[R1S_G];                                      // the GL sums of the outputs finished in a round
+  auto step = [&](const float* pl, f32x2& accP, f32x2& accC, f32x2& accN, f32x2& fin) __attribute__((always_inline)) {
+    const float* sp = pl + tid + 2;
+    f32x2 w[3][2];
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) w[ty][k >> 1][k & 1] = sp[ty * R1S_SROW + k];
     }
-  };
-  auto step = [&](int d, f32x2* pa, f32x2* pb, f32x2* pc) __attribute__((always_inline)) {
-    // all 27 LDS reads of the step first (two waves per SIMD: latencies are hidden by issuing early, not by other
-    // waves), three independent accumulation chains, the next plane of s requested as soon as plane d - 1 is consumed
-    const vec* gq = grq - d;
-    vec g[27];
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
-      g[q] = gq[q * UW + q % 3];
-      g[9 + q] = gq[(9 + q) * UW + q % 3 - 1];
-      g[18 + q] = gq[(18 + q) * UW + q % 3 - 2];
+      const int ty = q / 3, k = q % 3;
+      if (k & 1) {
+        r1_mac<1>(accN, gl[q], w[ty][k >> 1]);
+        r1_mac<1>(accC, gl[9 + q], w[ty][k >> 1]);
+        r1_mac<1>(accP, gl[18 + q], w[ty][k >> 1]);
+      } else {
+        r1_mac<0>(accN, gl[q], w[ty][k >> 1]);
+        r1_mac<0>(accC, gl[9 + q], w[ty][k >> 1]);
+        r1_mac<0>(accP, gl[18 + q], w[ty][k >> 1]);
+      }
     }
-    vec acc0 = {}, acc1 = {}, acc2 = {};
+    fin = accP;
+    accP = (f32x2){0.f, 0.f};
+  };
+  // outputs d = e - 1 of round r - 1 (e = 6 (r - 1) + j): GL sum from `done`, GR sum from the ring
+  auto finish_as = [&](int r, auto mishc) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < 9; ++q) mac(acc0, pa[q], gl[q] + g[q]);
-    load_plane(d + 2, pa);
+    for (int j = 0; j < R1S_G; ++j) {
+      const int d = (r - 1) * R1S_G + j - 1;
+      if (d < 0 || d >= a.D) continue;
+      // (x - d < -2: the whole right half is in its zero wedge, no diagonal thread exists for it)
+      const f32x2 rv = ring[(d % (2 * R1S_G)) * R1S_COLS + tid];
+      const f32x2 acc = done[j] + (x - d >= -2 ? rv : (f32x2){0.f, 0.f});
 #pragma unroll
-    for (int q = 0; q < 9; ++q) {
-      mac(acc1, pb[q], gl[9 + q] + g[9 + q]);
-      mac(acc2, pc[q], gl[18 + q] + g[18 + q]);
-    }
-    const vec acc = acc0 + acc1 + acc2;
-#pragma unroll
-    for (int c = 0; c < CPT; ++c) {
-      float v = fmaf(acc[c], sc[c], bi[c]);
-      v = mish ? dv_act(v, DV_ACT_MISH) : fmaxf(v, v * slope);
-      if (c < nch) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ors, ooff, c * vol_bytes + d * plane_bytes, 0);
+      for (int c = 0; c < 2; ++c) {
+        float v = fmaf(acc[c], sc[c], bi[c]);
+        v = decltype(mishc)::value ? dv_act(v, DV_ACT_MISH) : fmaxf(v, v * slope);
+        // (a missing second channel lies beyond the descriptor's nch volumes: that store is dropped)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ors, ooff, c * vol_bytes + d * plane_b, 0);
+      }
     }
   };
+  auto finish = [&](int r) __attribute__((always_inline)) {
+    if (mish) finish_as(r, std::true_type{});
+    else finish_as(r, std::false_type{});
+  };
+  f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
 #pragma unroll 1
-  for (int d = 0; d < a.D; d += 3) {
-    step(d, sw[0], sw[1], sw[2]);
-    if (d + 1 < a.D) step(d + 1, sw[1], sw[2], sw[0]);
-    if (d + 2 < a.D) step(d + 2, sw[2], sw[0], sw[1]);
+  for (int r = 0; r < nrounds; ++r) {
+    if (r + 1 < nrounds) stage_fetch(r + 1);
+    if (r >= 1) finish(r);
+    const float* base = s_ring + (r & 1) * R1S_STAGE;
+    step(base, a0, a1, a2, done[0]);
+    step(base + 3 * R1S_SROW, a1, a2, a0, done[1]);
+    step(base + 6 * R1S_SROW, a2, a0, a1, done[2]);
+    step(base + 9 * R1S_SROW, a0, a1, a2, done[3]);
+    step(base + 12 * R1S_SROW, a1, a2, a0, done[4]);
+    step(base + 15 * R1S_SROW, a2, a0, a1, done[5]);
+    if (r + 1 < nrounds) stage_commit(r + 1);
+    __syncthreads();
   }
+  finish(nrounds);
 }
 
 // p = softmax over D of att [B, D, HW] with the arithmetic of concat_rows_kernel (max, sum of dv_exp_le0, one
@@ -309,15 +355,16 @@ extern "C" int dv_conv3d_rank1_filter_f32(const float* s, const float* gl, const
   Rank1Args a;
   a.s = s; a.gl = gl; a.gr = gr; a.ch_scale = ch_scale; a.ch_bias = ch_bias; a.out = out;
   a.B = B; a.D = D; a.H = H; a.W = W; a.Cout = Cout; a.act = act;
-  constexpr int CPT = R1_CPT;
-  a.ntx = (W + R1_XT - 1) / R1_XT;
-  a.ncg = (Cout + CPT - 1) / CPT;
-  DV_REQUIRE(D <= R1_DMAX, DV_ERR_UNSUPPORTED);               // the LDS image is sized for 48 disparities
+  DV_REQUIRE(D <= R1_DMAX, DV_ERR_UNSUPPORTED);               // a tile's diagonal range x - d has to fit 256 lanes
   DV_REQUIRE((size_t)27 * Cout * H * W * sizeof(float) <= 0x7fffffffull, DV_ERR_SHAPE);    // 31-bit offsets in a table
   DV_REQUIRE((size_t)Cout * D * H * W * sizeof(float) <= 0x7fffffffull && (size_t)D * H * W * sizeof(float) <= 0x7fffffffull,
              DV_ERR_SHAPE);
-  const long long blocks = (long long)B * H * a.ntx * a.ncg;
-  if (blocks <= 0 || blocks > 0x7fffffffLL) return DV_ERR_SHAPE;
-  hipLaunchKernelGGL(rank1_filter_conv_kernel<CPT>, dim3((unsigned)blocks), dim3(R1_XT), 0, (hipStream_t)stream, a);
+  // 256 diagonal + 256 straight threads per (row, pair of channels); x tiles whose u = x - d range fits the diagonal lanes
+  const int xt = W + 2 <= R1S_COLS ? W : ((R1S_COLS - (D - 1)) & ~3);
+  a.ntx = (W + xt - 1) / xt;
+  a.ncg = (Cout + 1) / 2;
+  const long long nb = (long long)B * H * a.ntx * a.ncg;
+  if (nb <= 0 || nb > 0x7fffffffLL) return DV_ERR_SHAPE;
+  hipLaunchKernelGGL(rank1_filter_split_kernel, dim3((unsigned)nb), dim3(512), 0, (hipStream_t)stream, a, xt);
   return dv_launch_status();
 }

@@ -471,7 +471,7 @@ class Rank1FilterPlan:
                                                                     _lib.ptr(self.scale), _lib.ptr(self.shift),
                                                                     out.data_ptr(), b, d, h, w, self.cout, self.act,
                                                                     _lib.stream_ptr()), "dv_conv3d_rank1_filter_f32"),
-                  valu=out.numel() * 27 * 3.0)       # per output and tap: one packed add lane + one packed fma lane
+                  valu=out.numel() * 27 * 4.0)       # per output and tap: two fma lanes (GL term, GR term)
         return out
 
 

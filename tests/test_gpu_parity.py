@@ -394,7 +394,7 @@ def _assert_loop_contract(model, sd, vol, used, x_T, seed, gt=None, traj_epe=1e-
     reference itself is confident (uncertainty < 3 px, acv_ddim.py:330) and scales with the spread of the
     distribution elsewhere (`frac_gt_bar`, loop_parity._stats): with these untrained weights the soft-argmax sits on
     a ~50 px wide distribution and amplifies the last bit of the fp32 cost 17x more than a trained network does
-    (measured split: tests/diag/diag_split.py).  EPE is asserted unscaled.  Returns the report."""
+    (measured split: tools/diag/diag_split.py).  EPE is asserted unscaled.  Returns the report."""
     from oracle import loop_parity as LP
     gt = used if gt is None else gt                     # fixtures without ground truth: EPE against `used`
     orc = O.ACVDiffusionOracle(sd)

@@ -1,7 +1,7 @@
 """Where does the 1.3e-4 px mean distance between the HIP step and the oracle step come from?  Full size, pair 0,
 DDIM step 1.  Splits it into the aggregation stack (26 conv layers -> cost) and the regression tail (trilinear x4,
 softmax over 192 bins, soft-argmax) by crossing the two implementations, and measures both sides against float64.
-    python tests/diag/diag_split.py            (GPU box; prints one JSON line)"""
+    python tools/diag/diag_split.py            (GPU box; prints one JSON line)"""
 import json
 import sys
 from pathlib import Path

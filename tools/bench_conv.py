@@ -19,6 +19,8 @@ LAYERS = {  # name: (kind, cin, cout, k, stride, (D,H,W))
     "dc64": ("deconv", 64, 32, 3, 2, (24, 64, 120)),
     "dc128r": ("deconv_res", 128, 64, 3, 2, (12, 32, 60)),
     "dc64r": ("deconv_res", 64, 32, 3, 2, (24, 64, 120)),
+    "dc128x": ("deconv_redir", 128, 64, 3, 2, (12, 32, 60)),
+    "dc64x": ("deconv_redir", 64, 32, 3, 2, (24, 64, 120)),
     "k1_32": ("conv", 32, 32, 1, 1, (48, 128, 240)),
     "k1_64": ("conv", 64, 64, 1, 1, (24, 64, 120)),
 }
@@ -33,6 +35,11 @@ for n in names:
         w = torch.randn(cout, cin, k, k, k, device=dev) * 0.05
         plan = S.Conv3dPlan(w, bn, stride=s, act=S.ACT_RELU)
         flops = 2.0 * B * cout * cin * k ** 3 * (dims[0] // s) * (dims[1] // s) * (dims[2] // s)
+    elif kind == "deconv_redir":
+        w = torch.randn(cin, cout, 3, 3, 3, device=dev) * 0.05
+        rw = torch.randn(cout, cout, 1, 1, 1, device=dev) * 0.1
+        plan = S.Deconv3dPlan(w, bn, act=S.ACT_RELU, redir=(rw, tuple(torch.rand(cout, device=dev) + 0.5 for _ in range(4))))
+        flops = 2.0 * B * cout * cin * 27 * dims[0] * dims[1] * dims[2] + 2.0 * B * cout * cout * 8 * dims[0] * dims[1] * dims[2]
     else:
         w = torch.randn(cin, cout, 3, 3, 3, device=dev) * 0.05
         plan = S.Deconv3dPlan(w, bn, act=S.ACT_RELU)
@@ -40,6 +47,9 @@ for n in names:
     if kind == "deconv_res":
         res = torch.randn(B, cout, *(2 * d for d in dims), device=dev)
         run = lambda: plan(x, residual=res)
+    elif kind == "deconv_redir":
+        res = torch.randn(B, cout, *(2 * d for d in dims), device=dev)
+        run = lambda: plan(x, skip=res)
     else:
         run = lambda: plan(x)
     y = run()

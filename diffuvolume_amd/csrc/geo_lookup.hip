@@ -27,6 +27,14 @@ __device__ __forceinline__ void sample_pos(float x, int n, int& i0, float& w0, f
   w1 = ix - fl;            // weight of i0+1
 }
 
+// Round 3: the taps of a pixel overlap -- level 0 touches disparities floor(d) - 5 .. floor(d) + 6 and level 1 (pairs of
+// them) 2 floor(d/2) - 10 .. 2 floor(d/2) + 13 -- so a thread first copies the 24 entries dlo .. dlo + 23, dlo =
+// 2 floor(d/2) - 10, of a channel (and once of its noise row) into a column of LDS that only it touches, and every tap
+// reads from there by its own index (the sample positions keep the reference's float arithmetic, so an index may sit
+// one off the integer expectation: the window has room for that).  24 gathers per channel instead of 54: the gathers
+// are what the kernel costs when neighbouring pixels disagree about d (each lane then pulls its own cache line).
+constexpr int GEO_WIN = 24;
+
 template <int R>
 __global__ __launch_bounds__(256) void geo_lookup_kernel(const float* __restrict__ geo,
                                                          const float* __restrict__ corr0,
@@ -37,7 +45,11 @@ __global__ __launch_bounds__(256) void geo_lookup_kernel(const float* __restrict
                                                          float* __restrict__ out, int C, int D, int h, int w,
                                                          int W2, size_t npix) {
   constexpr int T = 2 * R + 1;
-  const size_t n = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  static_assert(R == 4, "window sized for radius 4");
+  __shared__ float gwin[GEO_WIN * 256];
+  __shared__ float nwin[GEO_WIN * 256];
+  const int tid = threadIdx.x;
+  const size_t n = (size_t)blockIdx.x * blockDim.x + tid;
   if (n >= npix) return;
   const size_t hw = (size_t)h * w;
   const size_t b = n / hw, p = n - b * hw;
@@ -47,41 +59,62 @@ __global__ __launch_bounds__(256) void geo_lookup_kernel(const float* __restrict
   const int W2b = W2 / 2, D1 = D / 2;
   const int nch = 2 * (C * T + T);
   float* o = out + b * nch * hw + p;                    // + channel * hw
-  auto noi0 = [&](int i) { return nrow[i]; };
-  auto noi1 = [&](int i) { return (nrow[2 * i] + nrow[2 * i + 1]) * 0.5f; };
-  // ---- level 0 ----
+  const int dlo = 2 * (int)floorf(d * 0.5f) - 10;
+  float* gw = gwin + tid;                               // entry k at gw[k * 256]
+  float* nw = nwin + tid;
+#pragma unroll
+  for (int k = 0; k < GEO_WIN; ++k) nw[k * 256] = (unsigned)(dlo + k) < (unsigned)D ? nrow[dlo + k] : 0.f;
+  // sample positions of the 2 x 9 taps (the reference's arithmetic), as window slots
+  int s0[T], s1[T];
+  float a0[T], b0[T], a1[T], b1[T];
+  bool ok10[T], ok11[T];                                // level 1: pooled entries i0, i0 + 1 inside [0, D / 2)
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    int i0;
+    sample_pos(d + (float)(t - R), D, i0, a0[t], b0[t]);
+    s0[t] = i0 - dlo;                                   // entries s0, s0 + 1 (5 .. 18 by construction)
+    sample_pos(d / 2.0f + (float)(t - R), D1, i0, a1[t], b1[t]);
+    s1[t] = 2 * i0 - dlo;                               // entries s1 .. s1 + 3 (0 .. 23)
+    ok10[t] = (unsigned)i0 < (unsigned)D1;
+    ok11[t] = (unsigned)(i0 + 1) < (unsigned)D1;
+    s0[t] = s0[t] < 0 ? 0 : (s0[t] > GEO_WIN - 2 ? GEO_WIN - 2 : s0[t]);     // (never taken: keeps the reads in the column)
+    s1[t] = s1[t] < 0 ? 0 : (s1[t] > GEO_WIN - 4 ? GEO_WIN - 4 : s1[t]);
+  }
+  // noise factors per tap: entries outside [0, D) are zero in both windows, which is the reference's zero padding
+  float n00[T], n01[T], n10[T], n11[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    n00[t] = nw[s0[t] * 256];
+    n01[t] = nw[(s0[t] + 1) * 256];
+    n10[t] = ok10[t] ? (nw[s1[t] * 256] + nw[(s1[t] + 1) * 256]) * 0.5f : 0.f;      // (an odd D has one entry past the pairs)
+    n11[t] = ok11[t] ? (nw[(s1[t] + 2) * 256] + nw[(s1[t] + 3) * 256]) * 0.5f : 0.f;
+  }
+  float* o1 = o + (size_t)(C * T + T) * hw;
+  for (int c = 0; c < C; ++c) {
+    const float* gc = g + (size_t)c * D * hw;
+#pragma unroll
+    for (int k = 0; k < GEO_WIN; ++k) gw[k * 256] = (unsigned)(dlo + k) < (unsigned)D ? gc[(size_t)(dlo + k) * hw] : 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const float v0 = gw[s0[t] * 256] * n00[t], v1 = gw[(s0[t] + 1) * 256] * n01[t];
+      o[(size_t)(c * T + t) * hw] = v0 * a0[t] + v1 * b0[t];
+      const float u0 = ((gw[s1[t] * 256] + gw[(s1[t] + 1) * 256]) * 0.5f) * n10[t];
+      const float u1 = ((gw[(s1[t] + 2) * 256] + gw[(s1[t] + 3) * 256]) * 0.5f) * n11[t];
+      o1[(size_t)(c * T + t) * hw] = u0 * a1[t] + u1 * b1[t];
+    }
+  }
+  // the two correlation rows (one gather pair per tap each)
+#pragma unroll
   for (int t = 0; t < T; ++t) {
     int i0; float w0, w1;
-    sample_pos(d + (float)(t - R), D, i0, w0, w1);
-    const bool ok0 = i0 >= 0 && i0 < D, ok1 = i0 + 1 >= 0 && i0 + 1 < D;
-    const float n0 = ok0 ? noi0(i0) : 0.f, n1 = ok1 ? noi0(i0 + 1) : 0.f;
-    for (int c = 0; c < C; ++c) {
-      const float v0 = ok0 ? g[((size_t)c * D + i0) * hw] * n0 : 0.f;
-      const float v1 = ok1 ? g[((size_t)c * D + i0 + 1) * hw] * n1 : 0.f;
-      o[(size_t)(c * T + t) * hw] = v0 * w0 + v1 * w1;
-    }
     sample_pos(cx - d + (float)(t - R), W2, i0, w0, w1);
     const float* cr = corr0 + n * W2;
     const float c0 = (i0 >= 0 && i0 < W2) ? cr[i0] : 0.f, c1 = (i0 + 1 >= 0 && i0 + 1 < W2) ? cr[i0 + 1] : 0.f;
     o[(size_t)(C * T + t) * hw] = c0 * w0 + c1 * w1;
-  }
-  // ---- level 1 (pairs of disparities averaged) ----
-  float* o1 = o + (size_t)(C * T + T) * hw;
-  for (int t = 0; t < T; ++t) {
-    int i0; float w0, w1;
-    sample_pos(d / 2.0f + (float)(t - R), D1, i0, w0, w1);
-    const bool ok0 = i0 >= 0 && i0 < D1, ok1 = i0 + 1 >= 0 && i0 + 1 < D1;
-    const float n0 = ok0 ? noi1(i0) : 0.f, n1 = ok1 ? noi1(i0 + 1) : 0.f;
-    for (int c = 0; c < C; ++c) {
-      const float* gc = g + (size_t)c * D * hw;
-      const float v0 = ok0 ? ((gc[(size_t)(2 * i0) * hw] + gc[(size_t)(2 * i0 + 1) * hw]) * 0.5f) * n0 : 0.f;
-      const float v1 = ok1 ? ((gc[(size_t)(2 * i0 + 2) * hw] + gc[(size_t)(2 * i0 + 3) * hw]) * 0.5f) * n1 : 0.f;
-      o1[(size_t)(c * T + t) * hw] = v0 * w0 + v1 * w1;
-    }
     sample_pos(cx / 2.0f - d / 2.0f + (float)(t - R), W2b, i0, w0, w1);
-    const float* cr = corr1 + n * W2b;
-    const float c0 = (i0 >= 0 && i0 < W2b) ? cr[i0] : 0.f, c1 = (i0 + 1 >= 0 && i0 + 1 < W2b) ? cr[i0 + 1] : 0.f;
-    o1[(size_t)(C * T + t) * hw] = c0 * w0 + c1 * w1;
+    const float* cr1 = corr1 + n * W2b;
+    const float e0 = (i0 >= 0 && i0 < W2b) ? cr1[i0] : 0.f, e1 = (i0 + 1 >= 0 && i0 + 1 < W2b) ? cr1[i0 + 1] : 0.f;
+    o1[(size_t)(C * T + t) * hw] = e0 * w0 + e1 * w1;
   }
 }
 

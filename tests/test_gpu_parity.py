@@ -545,6 +545,28 @@ def test_igev_geo_filter_lookup_oracle_kitti_size():
     torch.testing.assert_close(out.cpu(), ref, atol=3e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("d", [48, 13])
+def test_igev_geo_filter_lookup_window_edges(d):
+    """The lookup copies the 24 disparity entries around a pixel's d into a private window (csrc/geo_lookup.hip): exact
+    integers (where the reference's float sample position may land on either side of the integer), disparities at and
+    beyond both ends of the range, and an odd number of disparities (one entry past the pooled pairs)."""
+    from diffuvolume_amd.geometry_ddim import Combined_Geo_Encoding_Volume
+    from oracle import igev_oracle as IO
+    b, c, h, w = 1, 8, 6, 40
+    gen = _gen(64, f"edges{d}")
+    geo = torch.randn(b, c, d, h, w, generator=gen)
+    f1, f2 = torch.randn(b, 16, h, w, generator=gen), torch.randn(b, 16, h, w, generator=gen)
+    disp = torch.rand(b, 1, h, w, generator=gen) * (d + 12) - 6                       # -6 .. d + 6
+    disp[:, :, 0] = torch.arange(w, dtype=torch.float32) - 4                           # integers, also out of range
+    disp[:, :, 1] = torch.arange(w, dtype=torch.float32) * 0.5 + 1e-6
+    disp[:, :, 2] = torch.nextafter(torch.arange(w, dtype=torch.float32), torch.tensor(-1.0))   # just below integers
+    coords = torch.arange(w, dtype=torch.float32).view(1, 1, 1, w).expand(b, 1, h, w).contiguous()
+    noisy = torch.rand(b, d, h, w, generator=gen)
+    ref = IO.geo_filter_lookup(geo, f1, f2, disp, coords, noisy)
+    out = Combined_Geo_Encoding_Volume(dev(f1), dev(f2), dev(geo))(dev(disp), dev(coords), dev(noisy))
+    torch.testing.assert_close(out.cpu(), ref, atol=3e-5, rtol=1e-5)
+
+
 @pytest.mark.parametrize("shape", [(1, 24, 3, 78, 78), (2, 96, 2, 40, 40), (1, 7, 2, 17, 33), (1, 130, 1, 16, 21),
                                    (1, 4, 1, 5, 2)])
 def test_igev_allpairs_corr_oracle(shape):

@@ -16,3 +16,4 @@ print(f"total kernel time {tot / 1e6:.1f} ms")
 for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:28]:
     print(f'{float(r["TotalDurationNs"]) / tot:6.3f} {int(r["Calls"]):6d} {float(r["AverageNs"]) / 1e3:9.1f} us  {r["Name"][:110]}')
 PY
+rm -rf $O/stats                          # raw trace

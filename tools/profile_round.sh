@@ -9,3 +9,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --no-kernel-timer > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --no-kernel-timer > /dev/null 2>&1
 python tools/make_pmc_traffic.py $O $T ${2:-}
+rm -rf $O/stats $O/pmc_fetch $O/pmc_write   # raw traces: tens of MB, the summaries are what is kept

@@ -137,13 +137,24 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
   };
   // weights by LDS-DMA, source quad XOR-swizzled with the row (conv3d_wino.hip); 16 pieces of 1 KB, four per wave
   const int dma_lo = (lane >> 2) * 16 + (((lane & 3) ^ ((lane >> 4) & 3)) * 4);
+  const int dma_voff = dma_lo * 4;                 // the lane part of a piece's source address: constant
   auto dma_u = [&](int c0, float* ub) __attribute__((always_inline)) {
-    const float* src = a.wpk + ((size_t)(c0 / KC) * a.nco + tc) * U_CHUNK + dma_lo;
+    const float* src = a.wpk + ((size_t)(c0 / KC) * a.nco + tc) * U_CHUNK;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int piece = wave + 4 * q;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 256),
-                                       (__attribute__((address_space(3))) void*)(ub + piece * 256), 16, 0, 0);
+      // inline asm, not __builtin_amdgcn_global_load_lds: the compiler treats the builtin as an LDS store that any later
+      // LDS access may alias and answers the next ds_write with s_waitcnt vmcnt(0) -- every chunk then waited for its
+      // own DMA (config 5: 593 -> 584 ms per 128 GRU iterations).  Completion is covered by the manual s_waitcnt vmcnt + barrier
+      // at the top of the next chunk.  Scalar piece base + constant lane offset, M0 handed back as found, one wait state
+      // between the M0 write and the DMA (conv3d_wino.hip; tests/test_isa_lint.py checks the compiled stream).
+      const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(ub + piece * 256);
+      const uint64_t gb = reinterpret_cast<uint64_t>(src + piece * 256);
+      const uint64_t gbs = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)gb) |
+                           ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(gb >> 32)) << 32);
+      unsigned m0_saved;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                   : "=&s"(m0_saved) : "s"(lds_addr), "v"(dma_voff), "s"(gbs) : "memory");
     }
   };
 
@@ -238,8 +249,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
       const int ks = g >> 2, p4 = g & 3;
       if (g + 1 < 4 * NKS) load_b(g + 1, (g + 1) & 1);
       if (p4 == 0 && ks + 1 < NKS) load_patch(ks + 1);
-      // staging in the shadow of the MFMAs: DMA, then 2 channels of LDS commit / refill per group
-      if (g == 0 && dma_ok) dma_u(c_dma, unxt);
+      // staging in the shadow of the MFMAs: 2 channels of LDS commit per group, then the weight DMA (after the commits:
+      // the waits the compiler puts in front of them are vmcnt counts that would otherwise take the DMA along), then
+      // 2 channels of refill per group
+      if (g == 4 && dma_ok) dma_u(c_dma, unxt);
       if (g < 4 && nxt) { commit_raw_cl(2 * g, rbn, vin); commit_raw_cl(2 * g + 1, rbn, vin); }
       if (g >= 4 && refill) { fetch_raw_cl(c_fetch, 2 * (g - 4), vin); fetch_raw_cl(c_fetch, 2 * (g - 4) + 1, vin); }
 #pragma unroll

@@ -135,7 +135,21 @@ for i in range(n):
 print("second pass cases", n, "failures", bad2)
 
 # ---- third pass: conv3d prologue / residual / split-fp16, refinement inputs, gated conv2d ----
-from diffuvolume_amd.pwcnet_ddim import groupwise_corr_pm, warp
+from diffuvolume_amd.pwcnet_ddim import groupwise_corr_pm
+
+
+def warp(x, disp):
+    """Right features sampled at x - disp (bilinear, zeros outside, samples touching the border masked) -- the
+    statement refine_inputs is checked against (KITTI12/models/submodule.py:137-176)."""
+    b, c, h, w = x.shape
+    xx = torch.arange(w, device=x.device, dtype=torch.float32).view(1, 1, 1, w).expand(b, 1, h, w)
+    yy = torch.arange(h, device=x.device, dtype=torch.float32).view(1, 1, h, 1).expand(b, 1, h, w)
+    gx = 2.0 * (xx - disp) / max(w - 1, 1) - 1.0
+    gy = 2.0 * yy / max(h - 1, 1) - 1.0
+    grid = torch.cat((gx, gy), 1).permute(0, 2, 3, 1)
+    out = F.grid_sample(x, grid)
+    mask = (F.grid_sample(torch.ones_like(x), grid) >= 0.999).float()
+    return out * mask
 bad3 = 0
 for i in range(n):
     cin, cout = random.choice([8, 32, 64]), random.choice([16, 32, 64])

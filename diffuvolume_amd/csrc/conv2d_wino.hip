@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
   const size_t plane = (size_t)a.H * a.W;
   const int plane_bytes = (int)(plane * sizeof(float));      // < 2^31 (checked by the host)
   const int n_in = a.Cin;
+  const int n_chunk = (n_in + w2::KC - 1) / w2::KC;
 
   // ---- raw staging plan (as conv3d_wino.hip): buffer loads, zero padding and channel tail from the range check ----
   unsigned sob[NS];
@@ -111,21 +112,39 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
   }
   typedef float RawSet[KC][NS];
   RawSet vinA, vinB;      // (vinB is only used by the deep variant)
-  auto fetch_raw_cl = [&](int c0, int cl, RawSet& vin) __attribute__((always_inline)) {
-    const int c = c0 + cl;
-    const bool cok = c < n_in;
-    // source tensor of channel c in the virtual concatenation (scalar selects)
-    const int k = (c >= a.cend[0]) + (c >= a.cend[1]) + (c >= a.cend[2]);
-    const int cs = k == 0 ? 0 : a.cend[k - 1], cw = a.cend[k] - cs;
-    const float* base = cok ? a.src[k] + ((size_t)b * cw + (c - cs)) * plane : a.src[0];
-    const uint64_t ba = reinterpret_cast<uint64_t>(base);
-    const uint64_t bu = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ba) |
-                        ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ba >> 32)) << 32);
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(bu), 0,
-                                                      __builtin_amdgcn_readfirstlane(cok ? plane_bytes : 0), 0x00020000);
+  // Channels are fetched strictly in order (chunk after chunk, also past the end: a channel >= Cin gets a descriptor with
+  // zero records and costs no memory traffic), so the position in the virtual concatenation is running scalar state:
+  // the byte address of the next channel plane, the channels left in its source, and a queue of the sources to come.
+  // Everything is selects on the scalar unit -- no kernarg loads, no 64-bit multiplies and no branch per channel (the
+  // first version looked the source up per channel: two dependent s_load round trips, each closed by an
+  // s_waitcnt lgkmcnt(0) that also drained the LDS queue, and ~40 scalar instructions in four basic blocks between
+  // every two MFMA groups).
+  auto sgpr64 = [](uint64_t v) __attribute__((always_inline)) {
+    return (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v) |
+           ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32);
+  };
+  const int cw0 = a.cend[0], cw1 = a.cend[1] - a.cend[0], cw2 = a.cend[2] - a.cend[1], cw3 = a.cend[3] - a.cend[2];
+  uint64_t fb = sgpr64(reinterpret_cast<uint64_t>(a.src[0] + (size_t)b * cw0 * plane));
+  uint64_t nb1 = sgpr64(reinterpret_cast<uint64_t>(a.src[1] + (size_t)b * cw1 * plane));
+  uint64_t nb2 = sgpr64(reinterpret_cast<uint64_t>(a.src[2] + (size_t)b * cw2 * plane));
+  uint64_t nb3 = sgpr64(reinterpret_cast<uint64_t>(a.src[3] + (size_t)b * cw3 * plane));
+  constexpr int NEVER = 0x7fffffff;                 // an unused source slot: its counter never reaches zero
+  int left = cw0, nl1 = cw1 > 0 ? cw1 : NEVER, nl2 = cw2 > 0 ? cw2 : NEVER, nl3 = cw3 > 0 ? cw3 : NEVER;
+  int fc = 0;
+  auto fetch_raw_cl = [&](int /*c0*/, int cl, RawSet& vin) __attribute__((always_inline)) {
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(fb), 0, fc < n_in ? plane_bytes : 0,
+                                                      0x00020000);
 #pragma unroll
     for (int i = 0; i < NS; ++i)
       vin[cl][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)sob[i], 0, 0));
+    ++fc;
+    --left;
+    fb += (uint64_t)(unsigned)plane_bytes;
+    const bool sw = left == 0;                      // source exhausted: the queue moves up
+    fb = sw ? nb1 : fb;   left = sw ? nl1 : left;
+    nb1 = sw ? nb2 : nb1; nl1 = sw ? nl2 : nl1;
+    nb2 = sw ? nb3 : nb2; nl2 = sw ? nl3 : nl2;
+    nl3 = sw ? NEVER : nl3;
   };
   auto fetch_raw = [&](int c0, RawSet& vin) __attribute__((always_inline)) {
 #pragma unroll
@@ -138,8 +157,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
   // weights by LDS-DMA, source quad XOR-swizzled with the row (conv3d_wino.hip); 16 pieces of 1 KB, four per wave
   const int dma_lo = (lane >> 2) * 16 + (((lane & 3) ^ ((lane >> 4) & 3)) * 4);
   const int dma_voff = dma_lo * 4;                 // the lane part of a piece's source address: constant
-  auto dma_u = [&](int c0, float* ub) __attribute__((always_inline)) {
-    const float* src = a.wpk + ((size_t)(c0 / KC) * a.nco + tc) * U_CHUNK;
+  // the weight chunks are copied strictly in order too: a running scalar pointer to this wave's first piece of the next
+  // chunk (a chunk past the end re-copies the last one: the staging in `chunk` is issued unconditionally)
+  uint64_t ud = sgpr64(reinterpret_cast<uint64_t>(a.wpk + (size_t)tc * U_CHUNK + wave * 256));
+  const uint64_t ud_step = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane(a.nco * U_CHUNK * (int)sizeof(float));
+  int ud_left = n_chunk - 1;                         // advances left before the pointer stays on the last chunk
+  auto dma_u = [&](int /*c0*/, float* ub) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int piece = wave + 4 * q;
@@ -149,13 +172,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
       // at the top of the next chunk.  Scalar piece base + constant lane offset, M0 handed back as found, one wait state
       // between the M0 write and the DMA (conv3d_wino.hip; tests/test_isa_lint.py checks the compiled stream).
       const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(ub + piece * 256);
-      const uint64_t gb = reinterpret_cast<uint64_t>(src + piece * 256);
-      const uint64_t gbs = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)gb) |
-                           ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(gb >> 32)) << 32);
+      const uint64_t gbs = ud + (uint64_t)(q * 4 * 256 * sizeof(float));
       unsigned m0_saved;
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
                    : "=&s"(m0_saved) : "s"(lds_addr), "v"(dma_voff), "s"(gbs) : "memory");
     }
+    ud += ud_left > 0 ? ud_step : 0;
+    --ud_left;
   };
 
   // this lane's 4x4 patch: tile (row j&1, column j>>1) of the wave's four rows, channel ks*4 + kq;  B rows (kq, j)
@@ -170,12 +193,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
 #pragma unroll
   for (int cl = 0; cl < KC; ++cl) commit_raw_cl(cl, raw_s, vinA);
   if (DEEP) {
-    if (KC < n_in) {
-      dma_u(KC, u_s + U_CHUNK);
-      fetch_raw(KC, vinB);
-    }
-    if (2 * KC < n_in) fetch_raw(2 * KC, vinA);
-  } else if (KC < n_in) {
+    dma_u(KC, u_s + U_CHUNK);
+    fetch_raw(KC, vinB);
+    fetch_raw(2 * KC, vinA);
+  } else {
     fetch_raw(KC, vinA);
   }
 
@@ -184,18 +205,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
   auto chunk = [&](int c0, int cur, const float* ub, float* unxt, RawSet& vin) __attribute__((always_inline)) {
     // this chunk's weights (DMA) have to be in LDS; the loads issued after that DMA may stay in flight: the raw loads
     // of the next chunk (shallow), or raw + DMA + raw of the next two (deep)
-    if (DEEP) {
-      if (c0 + 2 * KC < n_in) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KC * NS + 4) : "memory");
-      else if (c0 + KC < n_in) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KC * NS + 4) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      if (c0 + KC < n_in) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KC * NS) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    // The chunk body has NO branch: the staging of the chunks to come is issued whether or not they exist (a channel
+    // past the end is a zero-record descriptor, a weight chunk past the end re-copies the last one into a buffer nobody
+    // reads), so the wait count is the same in every chunk and the whole body is one scheduling region -- with a uniform
+    // branch per staging step the MFMA stream was cut into 8-instruction basic blocks.
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEEP ? 2 * KC * NS + 4 : KC * NS) : "memory");
     __syncthreads();
-    const bool nxt = c0 + KC < n_in;
-    const bool dma_ok = DEEP ? c0 + 2 * KC < n_in : nxt;
-    const bool refill = DEEP ? c0 + 3 * KC < n_in : c0 + 2 * KC < n_in;
+    constexpr bool nxt = true, dma_ok = true, refill = true;
     const int c_dma = c0 + (DEEP ? 2 : 1) * KC, c_fetch = c0 + (DEEP ? 3 : 2) * KC;
     float* rbn = raw_s + (cur ^ 1) * RAW_FLOATS;
     const float* rb = raw_s + cur * RAW_FLOATS + patch_lo;
@@ -280,6 +296,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
     for (int c0 = 0; c0 < n_in; c0 += KC, cur ^= 1)
       chunk(c0, cur, u_s + cur * U_CHUNK, u_s + (cur ^ 1) * U_CHUNK, vinA);
   }
+
+  // the last chunks' surplus weight DMA must have landed before this block's LDS can be given to another one
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---- epilogue: Y = At M A per tile; a lane (cout j, tiles 4kq..4kq+3) holds 4 consecutive x of four rows ----
   const int yb = y0 + 4 * wave, xb = x0 + 4 * kq;

@@ -61,6 +61,16 @@ struct WG {
 };
 namespace wg {
 constexpr int U_CHUNK = 3 * 2 * 4 * 16 * 16;   // packed floats per (chunk, co block) = the LDS image, 24 KB
+// Branch-free chunk body: the staging of the chunks to come is issued whether or not they exist (channels past the end
+// are zero-record descriptors, a weight chunk past the end re-copies the last one), so the body is one scheduling region.
+#ifndef DV_WINO_BF
+#define DV_WINO_BF 0
+#endif
+constexpr bool BF = DV_WINO_BF;
+#ifndef DV_WINO_DMA_G
+#define DV_WINO_DMA_G 0
+#endif
+constexpr int DMA_G = DV_WINO_DMA_G;            // MFMA group of a chunk in which the next chunk's weight DMA is issued
 }
 
 struct WinoArgs {
@@ -173,7 +183,9 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
     // piece base on the scalar unit (SGPR pair), lane offset in one loop-invariant VGPR: a 64-bit vector add per piece
     // (v_lshl_add_u64) is an isolated vector-ALU instruction in the MFMA stream -- the matrix pipe drains for it
     // (~60 cycles each, tools/probes/mfma_f32_neighbours.hip)
-    const float* src = a.wpk + ((size_t)(c0 >> 2) * a.nco + tc) * U_CHUNK;
+    const int n_chunk = (a.Cin + KC - 1) / KC;
+    const int ch = (!wg::BF || (c0 >> 2) < n_chunk) ? (c0 >> 2) : n_chunk - 1;
+    const float* src = a.wpk + ((size_t)ch * a.nco + tc) * U_CHUNK;
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
       const int piece = wave + 4 * q;
@@ -231,20 +243,20 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
   fetch_raw(0);
   dma_u(0, u_s);
   commit_raw(raw_s);
-  if (KC < a.Cin) fetch_raw(KC);
+  if (wg::BF || KC < a.Cin) fetch_raw(KC);
   // one chunk: `vin` holds the raw brick of chunk c0+KC on entry and that of chunk c0+2*KC on exit
   auto chunk = [&](int c0, int cur) __attribute__((always_inline)) {
     // this chunk's weights (DMA, issued at the start of the previous chunk) have to be in LDS; the raw loads issued
     // after them (KC*NS per thread, for chunk c0+KC) may stay in flight.  After the barrier every wave is done with
     // the other pair of buffers and this chunk's raw brick is complete.
-    if (c0 + KC < a.Cin) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KC * NS) : "memory");
+    if (wg::BF || c0 + KC < a.Cin) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KC * NS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // The staging of the next chunk (weight DMA, LDS commit of the raw registers, their refill two chunks ahead) is
     // spread over the first MFMA groups below: between two MFMAs of a wave there are issue slots the matrix pipe does
     // not need, and instructions placed there cost nothing, while a staging phase in front of the stream delays the
     // first MFMA of every chunk.
-    const bool nxt = c0 + KC < a.Cin, refill = c0 + 2 * KC < a.Cin;
+    const bool nxt = wg::BF || c0 + KC < a.Cin, refill = wg::BF || c0 + 2 * KC < a.Cin;
     // MFMA stream: 12 groups (kd, position quad) of 8*MTW MFMAs.  The B fragments of group g+1, the raw patches of
     // the next plane(s) and their transform are written in the shadow of group g; the final order is the compiler's
     // (pinning it with sched_barrier around every group measured 1-2.5 % slower once the staging was spread out).
@@ -317,8 +329,9 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
       const int kd = g >> 2, p4 = g & 3;
       if (g + 1 < 12) load_b(g + 1, (g + 1) & 1);
       if (p4 == 0 && kd < 2) load_patch(kd + 1);
-      if (g == 0 && nxt) dma_u(c0 + KC, u_s + (cur ^ 1) * U_CHUNK);
+      if (g == wg::DMA_G && wg::DMA_G < 2 + KC && nxt) dma_u(c0 + KC, u_s + (cur ^ 1) * U_CHUNK);
       if (g >= 2 && g < 2 + KC && nxt) commit_next_cl(g - 2);
+      if (g == wg::DMA_G && wg::DMA_G >= 2 + KC && nxt) dma_u(c0 + KC, u_s + (cur ^ 1) * U_CHUNK);
       // (all KC*NS refill loads in ONE group would let the compiler count them exactly -- its waits before the commits
       // become vmcnt(11), (10), ... instead of (2), (1), (0) per group -- but bunching the loads costs more than the
       // coarser waits: 46.8 vs 47.4 pairs/s)
@@ -346,6 +359,8 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
 #pragma unroll 1
     for (int c0 = 0; c0 < a.Cin; c0 += KC, cur ^= 1) chunk(c0, cur);
   }
+
+  if (wg::BF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus weight DMA of the last chunk
 
   // ---- epilogue: Y = At M A per tile, BN scale/bias, residual, activation.  M index m = tile (row m&1, column
   // m>>1), so a lane (cout j, tiles 4*kq .. 4*kq+3) holds tile columns 2kq, 2kq+1 of both tile rows: 4 consecutive x

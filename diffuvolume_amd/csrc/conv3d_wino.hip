@@ -64,11 +64,11 @@ constexpr int U_CHUNK = 3 * 2 * 4 * 16 * 16;   // packed floats per (chunk, co b
 // Branch-free chunk body: the staging of the chunks to come is issued whether or not they exist (channels past the end
 // are zero-record descriptors, a weight chunk past the end re-copies the last one), so the body is one scheduling region.
 #ifndef DV_WINO_BF
-#define DV_WINO_BF 0
+#define DV_WINO_BF 1
 #endif
 constexpr bool BF = DV_WINO_BF;
 #ifndef DV_WINO_DMA_G
-#define DV_WINO_DMA_G 0
+#define DV_WINO_DMA_G 6
 #endif
 constexpr int DMA_G = DV_WINO_DMA_G;            // MFMA group of a chunk in which the next chunk's weight DMA is issued
 }

@@ -1,0 +1,584 @@
+// K11w: the 3x3, dilation-1, stride-1 2-D convolutions (IGEV's ConvGRU / motion encoder / heads, KITTI15/core/update.py;
+// the residual blocks of the 2-D feature CNNs, SceneFlow/models/submodule.py:21-24,:192-215) in the Winograd
+// F(2x2, 3x3) form on v_mfma_f32_16x16x4_f32 -- the 2-D sibling of conv3d_wino.hip (same transforms in registers,
+// same XOR-swizzled LDS-DMA weight image, same staging spread into the MFMA groups), with the epilogue of
+// conv2d.hip: per-channel scale/bias, residual, activation (incl. sigmoid / tanh), `mul` and the GRU blend, and up
+// to four input tensors read as one virtual channel concatenation.
+//
+// Block = 4 waves = 16 x 16 outputs x 32 output channels; wave w owns rows 4w..4w+3: its MFMA tile is M = 16 Winograd
+// tiles (2 tile rows x 8 tile columns), N = 16 output channels, K = 4 input channels.  A chunk is 8 input channels =
+// two k-steps x 16 positions x 2 N-tiles = 64 MFMAs per wave; raw brick (18 x 18 per channel) and weights are
+// double-buffered in LDS (62 KB, two blocks per CU).
+
+#include <type_traits>
+
+#include "dv_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace w2 {
+constexpr int KC = 8, NKS = 2, NT = 2, TH = 16, TW = 16;
+constexpr int IY = TH + 2, IX = TW + 2;
+constexpr int PRAW = IY * IX;                 // 324 raw positions per channel
+constexpr int RX = 24;                        // row stride; with a channel stride = 32 mod 64 the 16 tiles x 2 channels of
+constexpr int RAWP = 480;                     // a 32-lane ds_read_b64 cover the 64 banks once (see conv3d_wino.hip)
+constexpr int RAW_FLOATS = KC * RAWP;
+constexpr int U_CHUNK = NKS * NT * 4 * 16 * 16;   // packed floats per (chunk, co block) = the LDS image, 16 KB
+constexpr int NS = (PRAW + 255) / 256;
+// Vector staging (W % 4 == 0, dilation 1, 16-byte aligned sources): a brick row is fetched as the six aligned 16-byte
+// segments x0-4 .. x0+19 (each lies wholly inside or wholly outside the image, so the range check of the buffer load
+// still is the zero padding), one buffer_load_dwordx4 + one ds_write_b128 per lane and channel, and the two wave pairs
+// of the block take alternate channels: 4 loads + 4 LDS writes per wave and chunk instead of 16 + 16.  Every LDS /
+// vector-memory instruction of a wave costs the fp32 MFMA stream of its SIMD ~25 cycles whether or not it stalls
+// (ablations in profiles/r03_conv2d_wino_ablation.txt), so the instruction COUNT is what this buys.  The LDS brick keeps
+// the scalar layout (column 0 = x0-1, so that the 4x4 patches start on 8-byte boundaries: ds_read2_b64 on a 4-byte
+// boundary works on gfx950 but measured 70 % slower for the whole kernel): a lane writes (last float of its left
+// neighbour's segment, its own first three) -- one wave_shr:1 DPP move per segment.
+constexpr int VSEG = 6;                        // 16-byte segments per brick row
+constexpr int VROWS0 = 10;                     // brick rows staged by the first wave of a pair (60 lanes), 8 by the second
+constexpr int VDUMP = IY * RX;                 // a 16-byte slot past the brick for the idle lanes
+static_assert(VSEG * 4 == RX && VDUMP + 4 <= RAWP && VDUMP % 4 == 0, "vector staging layout");
+static_assert(RAWP >= IY * RX && RAWP % 64 == 32, "bank plan of the patch reads");
+static_assert((RAW_FLOATS + U_CHUNK) * 2 * 4 * 2 <= 160 * 1024, "two blocks per CU, both stages double-buffered");
+}  // namespace w2
+
+struct Wino2dArgs {
+  const float* src[4];    // sources of the virtual channel concatenation ([B,c_k,H,W] each)
+  int cend[4];            // cumulative channel count after each source (cend[3] == Cin)
+  const float* wpk;       // [Cin/8][Coutp/32][ks 2][nt 2][k 4][n 16][pos 16]
+  const float* ch_scale;
+  const float* ch_bias;
+  const float* residual;
+  const float* mul;
+  const float* blend_z;
+  const float* blend_h;
+  float* out;
+  int B, Cin, H, W, Cout;
+  int ntx, nty, nco;
+  int act, fast_ok;
+  int dil;                // dilation: the block works on one of the dil*dil sub-sampled images (a dilation-1 problem)
+  // two convolutions that read the same input in one launch (ConvGRU's z and r gates): output channels >= gsplit (a
+  // multiple of 32, 0 = off) belong to the second one, whose result / residual / mul tensors are [B, Cout - gsplit, H, W]
+  int gsplit;
+  const float* residual2;
+  const float* mul2;
+  float* out2;
+};
+
+// DEEP: the low-occupancy variant for launches that do not fill the chip (IGEV's 1/8 and 1/16 scales at batch 1):
+// with one block or less per CU nothing hides a chunk's memory latency, so the weight DMA runs two chunks ahead
+// (ring of three LDS images) and the raw loads three (two register sets).
+template <bool VEC> struct RawRegs { float v[w2::KC][w2::NS]; };
+template <> struct RawRegs<true> { f32x4 v[w2::KC / 2]; };
+
+template <bool DEEP, bool VEC>
+__global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
+  using namespace w2;
+  constexpr int NU = DEEP ? 3 : 2;
+  __shared__ __attribute__((aligned(1024))) float smem[NU * U_CHUNK + 2 * RAW_FLOATS];
+  float* u_s = smem;
+  float* raw_s = smem + NU * U_CHUNK;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, kq = lane >> 4;
+
+  // A 3x3 convolution with dilation d is d*d independent dilation-1 convolutions on the images sub-sampled at
+  // (ry + d*Y, rx + d*X): a block owns a 16x16 tile of ONE sub-image, and everything between the raw loads and the
+  // stores is the dilation-1 kernel.  The sub-image index is the fastest tile index, so the d*d blocks that share
+  // the same cache lines of input and output run side by side on one XCD.
+  unsigned t = dv_xcd_remap(blockIdx.x, gridDim.x);
+  const int dil = a.dil;
+  const int sg = t % (unsigned)(dil * dil); t /= (unsigned)(dil * dil);
+  const int ry = sg / dil, rx = sg - ry * dil;
+  const int tc = t % a.nco; t /= a.nco;       // the output-channel slices of a tile side by side too: one HBM read of the brick
+  const int tx = t % a.ntx; t /= a.ntx;
+  const int ty = t % a.nty;
+  const int b = t / a.nty;
+  const int x0 = tx * TW, y0 = ty * TH, co0 = tc * 32;          // in sub-image coordinates
+  const int Hs = (a.H - ry + dil - 1) / dil, Ws = (a.W - rx + dil - 1) / dil;   // size of this sub-image
+  if (y0 >= Hs || x0 >= Ws) return;                              // (the tile grid is that of the largest sub-image)
+
+  f32x4 acc[16][NT];
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[p][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const size_t plane = (size_t)a.H * a.W;
+  const int plane_bytes = (int)(plane * sizeof(float));      // < 2^31 (checked by the host)
+  const int n_in = a.Cin;
+  const int n_chunk = (n_in + w2::KC - 1) / w2::KC;
+
+  // ---- raw staging plan (as conv3d_wino.hip): buffer loads, zero padding and channel tail from the range check ----
+  constexpr int NSV = VEC ? 1 : NS;          // loads per lane and staging step
+  constexpr int STEPS = VEC ? KC / 2 : KC;   // staging steps per chunk: a channel (scalar) or a pair of channels (vector)
+  constexpr int LOADS = STEPS * NSV;         // vector-memory loads per lane and chunk
+  const int half = wave >> 1;                // vector staging: wave pair `half` takes channel 2*step + half
+  unsigned sob[NSV];
+  int lro[NSV];
+  if (VEC) {
+    const int wih = wave & 1;
+    const int yy = wih * VROWS0 + lane / VSEG, sg = lane - (lane / VSEG) * VSEG;
+    const bool valid = lane < (wih ? (IY - VROWS0) * VSEG : VROWS0 * VSEG);
+    const int y = y0 - 1 + yy, x = x0 - 4 + 4 * sg;
+    const bool ok = valid && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;   // W % 4 == 0: all four or none
+    sob[0] = ok ? (unsigned)(y * a.W + x) * 4u : 0x80000000u;
+    lro[0] = (valid && sg > 0 ? yy * RX + 4 * (sg - 1) : VDUMP) + half * RAWP;   // (the row's first segment only feeds its neighbour)
+  } else {
+#pragma unroll
+    for (int i = 0; i < NSV; ++i) {
+      const int r = tid + 256 * i;
+      const int yy = r / IX, xx = r - yy * IX;
+      const int y = ry + dil * (y0 - 1 + yy), x = rx + dil * (x0 - 1 + xx);
+      const bool ok = r < PRAW && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+      sob[i] = ok ? (unsigned)(y * a.W + x) * 4u : 0x80000000u;
+      lro[i] = r < PRAW ? yy * RX + xx : IX;                   // lanes past the brick write a column no patch reads
+    }
+  }
+  typedef RawRegs<VEC> RawSet;
+  RawSet vinA, vinB;      // (vinB is only used by the deep variant)
+  // Channels are fetched strictly in order (chunk after chunk, also past the end: a channel >= Cin gets a descriptor with
+  // zero records and costs no memory traffic), so the position in the virtual concatenation is running scalar state:
+  // the byte address of the next channel plane, the channels left in its source, and a queue of the sources to come.
+  // Everything is selects on the scalar unit -- no kernarg loads, no 64-bit multiplies and no branch per channel (the
+  // first version looked the source up per channel: two dependent s_load round trips, each closed by an
+  // s_waitcnt lgkmcnt(0) that also drained the LDS queue, and ~40 scalar instructions in four basic blocks between
+  // every two MFMA groups).
+  auto sgpr64 = [](uint64_t v) __attribute__((always_inline)) {
+    return (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v) |
+           ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32);
+  };
+  const int cw0 = a.cend[0], cw1 = a.cend[1] - a.cend[0], cw2 = a.cend[2] - a.cend[1], cw3 = a.cend[3] - a.cend[2];
+  uint64_t fb = sgpr64(reinterpret_cast<uint64_t>(a.src[0] + (size_t)b * cw0 * plane));
+  uint64_t nb1 = sgpr64(reinterpret_cast<uint64_t>(a.src[1] + (size_t)b * cw1 * plane));
+  uint64_t nb2 = sgpr64(reinterpret_cast<uint64_t>(a.src[2] + (size_t)b * cw2 * plane));
+  uint64_t nb3 = sgpr64(reinterpret_cast<uint64_t>(a.src[3] + (size_t)b * cw3 * plane));
+  constexpr int NEVER = 0x7fffffff;                 // an unused source slot: its counter never reaches zero
+  int left = cw0, nl1 = cw1 > 0 ? cw1 : NEVER, nl2 = cw2 > 0 ? cw2 : NEVER, nl3 = cw3 > 0 ? cw3 : NEVER;
+  int fc = 0;
+  // descriptor words of the next channel in the sequence; the sequence moves on
+  auto next_channel = [&](uint64_t& base, int& records) __attribute__((always_inline)) {
+    base = fb;
+    records = fc < n_in ? plane_bytes : 0;
+    ++fc;
+    --left;
+    fb += (uint64_t)(unsigned)plane_bytes;
+    const bool sw = left == 0;                      // source exhausted: the queue moves up
+    fb = sw ? nb1 : fb;   left = sw ? nl1 : left;
+    nb1 = sw ? nb2 : nb1; nl1 = sw ? nl2 : nl1;
+    nb2 = sw ? nb3 : nb2; nl2 = sw ? nl3 : nl2;
+    nl3 = sw ? NEVER : nl3;
+  };
+  auto fetch_step = [&](int st, RawSet& vin) __attribute__((always_inline)) {
+    uint64_t base;
+    int records;
+    next_channel(base, records);
+    if constexpr (VEC) {
+      uint64_t base1;
+      int records1;
+      next_channel(base1, records1);
+      base = half ? base1 : base;                   // (wave-uniform selects)
+      records = half ? records1 : records;
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(base), 0, records, 0x00020000);
+      vin.v[st] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)sob[0], 0, 0));
+    } else {
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(base), 0, records, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < NSV; ++i)
+        vin.v[st][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)sob[i], 0, 0));
+    }
+  };
+  auto fetch_raw = [&](RawSet& vin) __attribute__((always_inline)) {
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) fetch_step(st, vin);
+  };
+  auto commit_step = [&](int st, float* rb, RawSet& vin) __attribute__((always_inline)) {
+    if constexpr (VEC) {
+      const f32x4 v = vin.v[st];
+      const float left_w = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[3]), 0x138 /* wave_shr:1 */,
+                                                                                 0xf, 0xf, false));
+      *reinterpret_cast<f32x4*>(rb + 2 * st * RAWP + lro[0]) = (f32x4){left_w, v[0], v[1], v[2]};
+    } else {
+#pragma unroll
+      for (int i = 0; i < NSV; ++i) rb[st * RAWP + lro[i]] = vin.v[st][i];
+    }
+  };
+  // weights by LDS-DMA, source quad XOR-swizzled with the row (conv3d_wino.hip); 16 pieces of 1 KB, four per wave
+  const int dma_lo = (lane >> 2) * 16 + (((lane & 3) ^ ((lane >> 4) & 3)) * 4);
+  const int dma_voff = dma_lo * 4;                 // the lane part of a piece's source address: constant
+  // the weight chunks are copied strictly in order too: a running scalar pointer to this wave's first piece of the next
+  // chunk (a chunk past the end re-copies the last one: the staging in `chunk` is issued unconditionally)
+  uint64_t ud = sgpr64(reinterpret_cast<uint64_t>(a.wpk + (size_t)tc * U_CHUNK + wave * 256));
+  const uint64_t ud_step = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane(a.nco * U_CHUNK * (int)sizeof(float));
+  int ud_left = n_chunk - 1;                         // advances left before the pointer stays on the last chunk
+  auto dma_u = [&](int /*c0*/, float* ub) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int piece = wave + 4 * q;
+      // inline asm, not __builtin_amdgcn_global_load_lds: the compiler treats the builtin as an LDS store that any later
+      // LDS access may alias and answers the next ds_write with s_waitcnt vmcnt(0) -- every chunk then waited for its
+      // own DMA (config 5: 593 -> 584 ms per 128 GRU iterations).  Completion is covered by the manual s_waitcnt vmcnt + barrier
+      // at the top of the next chunk.  Scalar piece base + constant lane offset, M0 handed back as found, one wait state
+      // between the M0 write and the DMA (conv3d_wino.hip; tests/test_isa_lint.py checks the compiled stream).
+      const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(ub + piece * 256);
+      const uint64_t gbs = ud + (uint64_t)(q * 4 * 256 * sizeof(float));
+      unsigned m0_saved;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                   : "=&s"(m0_saved) : "s"(lds_addr), "v"(dma_voff), "s"(gbs) : "memory");
+    }
+    ud += ud_left > 0 ? ud_step : 0;
+    --ud_left;
+  };
+
+  // this lane's 4x4 patch: tile (row j&1, column j>>1) of the wave's four rows, channel ks*4 + kq;  B rows (kq, j)
+  const int patch_lo = kq * RAWP + (4 * wave + 2 * (j & 1)) * RX + 2 * (j >> 1);
+  int b_lo[4];
+#pragma unroll
+  for (int p4 = 0; p4 < 4; ++p4) b_lo[p4] = (kq * 16 + j) * 16 + ((p4 ^ ((j >> 2) & 3)) * 4);
+
+  // ---- prologue.  Chunk k >= 1 travels in register set A (shallow) or set (k & 1 ? B : A) (deep) ----
+  fetch_raw(vinA);
+  dma_u(0, u_s);
+#pragma unroll
+  for (int st = 0; st < STEPS; ++st) commit_step(st, raw_s, vinA);
+  if (DEEP) {
+    dma_u(KC, u_s + U_CHUNK);
+    fetch_raw(vinB);
+    fetch_raw(vinA);
+  } else {
+    fetch_raw(vinA);
+  }
+
+  // one chunk.  `vin` holds the raw brick of chunk c0+KC on entry and is refilled for chunk c0+2*KC (deep: c0+3*KC);
+  // ub = LDS weight image of this chunk, unxt = target of the DMA issued in this chunk (chunk c0+KC, deep: c0+2*KC)
+  auto chunk = [&](int c0, int cur, const float* ub, float* unxt, RawSet& vin) __attribute__((always_inline)) {
+    // this chunk's weights (DMA) have to be in LDS; the loads issued after that DMA may stay in flight: the raw loads
+    // of the next chunk (shallow), or raw + DMA + raw of the next two (deep)
+    // The chunk body has NO branch: the staging of the chunks to come is issued whether or not they exist (a channel
+    // past the end is a zero-record descriptor, a weight chunk past the end re-copies the last one into a buffer nobody
+    // reads), so the wait count is the same in every chunk and the whole body is one scheduling region -- with a uniform
+    // branch per staging step the MFMA stream was cut into 8-instruction basic blocks.
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEEP ? 2 * LOADS + 4 : LOADS) : "memory");
+    __syncthreads();
+    constexpr bool nxt = true, dma_ok = true, refill = true;
+    const int c_dma = c0 + (DEEP ? 2 : 1) * KC;
+    float* rbn = raw_s + (cur ^ 1) * RAW_FLOATS;
+    const float* rb = raw_s + cur * RAW_FLOATS + patch_lo;
+    f32x2 d[4][2];
+    f32x4 bq[2][NT];
+    f32x2 vp[2][4][2];
+    auto load_patch = [&](int ks) __attribute__((always_inline)) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        d[r][0] = *reinterpret_cast<const f32x2*>(rb + ks * 4 * RAWP + r * RX);
+        d[r][1] = *reinterpret_cast<const f32x2*>(rb + ks * 4 * RAWP + r * RX + 2);
+      }
+    };
+    auto load_b = [&](int g, int slot) __attribute__((always_inline)) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        bq[slot][n] = *reinterpret_cast<const f32x4*>(ub + ((g >> 2) * NT + n) * (4 * 256) + b_lo[g & 3]);
+    };
+    auto transform = [&](int slot) __attribute__((always_inline)) {   // V = Bt d B, packed fp32 (conv3d_wino.hip)
+      // one asm statement = one dense burst of 16 packed adds (a vector instruction that arrives alone between two fp32
+      // MFMAs makes the shared pipe drain, ~60 cycles; ~5 inside a burst); the closing s_nop covers the VALU -> MFMA
+      // read hazard that gfx950 does not interlock (conv3d_wino.hip)
+      f32x2 t0, t1, t2, t3;
+      asm("v_pk_add_f32 %8, %12, %16 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+          "v_pk_add_f32 %9, %13, %17 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+          "v_pk_add_f32 %10, %14, %16\n\t"
+          "v_pk_add_f32 %11, %15, %17\n\t"
+          "v_pk_add_f32 %0, %8, %9 op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+          "v_pk_add_f32 %1, %9, %8 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]\n\t"
+          "v_pk_add_f32 %2, %10, %11 op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+          "v_pk_add_f32 %3, %11, %10 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]\n\t"
+          "v_pk_add_f32 %8, %16, %14 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+          "v_pk_add_f32 %9, %17, %15 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+          "v_pk_add_f32 %10, %14, %18 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+          "v_pk_add_f32 %11, %15, %19 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+          "v_pk_add_f32 %4, %8, %9 op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+          "v_pk_add_f32 %5, %9, %8 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]\n\t"
+          "v_pk_add_f32 %6, %10, %11 op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+          "v_pk_add_f32 %7, %11, %10 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]\n\t"
+          "s_nop 1"
+          : "=&v"(vp[slot][0][0]), "=&v"(vp[slot][0][1]), "=&v"(vp[slot][1][0]), "=&v"(vp[slot][1][1]),
+            "=&v"(vp[slot][2][0]), "=&v"(vp[slot][2][1]), "=&v"(vp[slot][3][0]), "=&v"(vp[slot][3][1]),
+            "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+          : "v"(d[0][0]), "v"(d[0][1]), "v"(d[1][0]), "v"(d[1][1]), "v"(d[2][0]), "v"(d[2][1]), "v"(d[3][0]), "v"(d[3][1]));
+    };
+    load_patch(0);
+    load_b(0, 0);
+    transform(0);
+#pragma unroll
+    for (int g = 0; g < 4 * NKS; ++g) {
+      const int ks = g >> 2, p4 = g & 3;
+      if (g + 1 < 4 * NKS) load_b(g + 1, (g + 1) & 1);
+      if (p4 == 0 && ks + 1 < NKS) load_patch(ks + 1);
+      // staging in the shadow of the MFMAs: 2 channels of LDS commit per group, then the weight DMA (after the commits:
+      // the waits the compiler puts in front of them are vmcnt counts that would otherwise take the DMA along), then
+      // 2 channels of refill per group
+      if (g == 4 && dma_ok) dma_u(c_dma, unxt);
+      if (g < 4 && nxt) {
+        if (VEC) commit_step(g, rbn, vin);
+        else { commit_step(2 * g, rbn, vin); commit_step(2 * g + 1, rbn, vin); }
+      }
+      if (g >= 4 && refill) {
+        if (VEC) fetch_step(g - 4, vin);
+        else { fetch_step(2 * (g - 4), vin); fetch_step(2 * (g - 4) + 1, vin); }
+      }
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc[p4 * 4 + e][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[ks & 1][p4][e >> 1][e & 1], bq[g & 1][n][e],
+                                                                    acc[p4 * 4 + e][n], 0, 0, 0);
+      if (p4 == 1 && ks + 1 < NKS) transform((ks + 1) & 1);
+    }
+  };
+  if (DEEP) {
+    // weight ring slot of chunk k = k % 3; raw LDS buffer k & 1; register set of chunk k+1 alternates B, A, B, ...
+    int iu = 0;
+#pragma unroll 1
+    for (int c0 = 0; c0 < n_in; c0 += 2 * KC) {
+      const int iu1 = iu == 2 ? 0 : iu + 1, iu2 = iu1 == 2 ? 0 : iu1 + 1;
+      chunk(c0, 0, u_s + iu * U_CHUNK, u_s + iu2 * U_CHUNK, vinB);
+      if (c0 + KC < n_in) chunk(c0 + KC, 1, u_s + iu1 * U_CHUNK, u_s + iu * U_CHUNK, vinA);
+      iu = iu2;
+    }
+  } else {
+    int cur = 0;
+#pragma unroll 1
+    for (int c0 = 0; c0 < n_in; c0 += KC, cur ^= 1)
+      chunk(c0, cur, u_s + cur * U_CHUNK, u_s + (cur ^ 1) * U_CHUNK, vinA);
+  }
+
+  // the last chunks' surplus weight DMA must have landed before this block's LDS can be given to another one
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- epilogue: Y = At M A per tile; a lane (cout j, tiles 4kq..4kq+3) holds 4 consecutive x of four rows ----
+  const int yb = y0 + 4 * wave, xb = x0 + 4 * kq;
+  if (yb >= Hs) return;
+  const bool fast = a.fast_ok && dil == 1 && x0 + TW <= a.W && yb + 4 <= a.H;
+  const float slope = a.act == DV_ACT_RELU ? 0.f : (a.act == DV_ACT_LEAKY ? 0.01f : 1.f);
+  const bool gen = a.act == DV_ACT_MISH || a.act == DV_ACT_SIGMOID || a.act == DV_ACT_TANH;
+  // a block's 32 output channels lie in one group (gsplit % 32 == 0): the group's tensors are chosen per block
+  const bool g2 = a.gsplit > 0 && co0 >= a.gsplit;
+  const int cog0 = g2 ? a.gsplit : 0, coutg = g2 ? a.Cout - a.gsplit : (a.gsplit > 0 ? a.gsplit : a.Cout);
+  float* const outp = g2 ? a.out2 : a.out;
+  const float* const resp = g2 ? a.residual2 : a.residual;
+  const float* const mulp = g2 ? a.mul2 : a.mul;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int co = co0 + n * 16 + j;
+    if (co >= a.Cout) continue;
+    const float sc = a.ch_scale ? a.ch_scale[co] : 1.f;
+    const float bi = a.ch_bias ? a.ch_bias[co] : 0.f;
+    const size_t cbase = (((size_t)b * coutg + (co - cog0)) * a.H + (ry + dil * yb)) * a.W + (rx + dil * xb);
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr) {
+      float yv[2][4];
+#pragma unroll
+      for (int tcx = 0; tcx < 2; ++tcx) {
+        const int i = tr + 2 * tcx;
+        float s0[4], s1[4];
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+          const float m0 = acc[px][n][i], m1 = acc[4 + px][n][i], m2 = acc[8 + px][n][i], m3 = acc[12 + px][n][i];
+          s0[px] = m0 + m1 + m2;
+          s1[px] = m1 - m2 - m3;
+        }
+        yv[0][2 * tcx] = s0[0] + s0[1] + s0[2];
+        yv[0][2 * tcx + 1] = s0[1] - s0[2] - s0[3];
+        yv[1][2 * tcx] = s1[0] + s1[1] + s1[2];
+        yv[1][2 * tcx + 1] = s1[1] - s1[2] - s1[3];
+      }
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int yr = 2 * tr + r;
+        const size_t o = cbase + (size_t)(dil * yr) * a.W;
+        if (fast) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaf(yv[r][e], sc, bi);
+          if (resp) v += *reinterpret_cast<const f32x4*>(resp + o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gen ? dv_act(v[e], a.act) : fmaxf(v[e], v[e] * slope);
+          if (mulp) v *= *reinterpret_cast<const f32x4*>(mulp + o);
+          if (a.blend_z) {
+            const f32x4 z = *reinterpret_cast<const f32x4*>(a.blend_z + o);
+            const f32x4 h = *reinterpret_cast<const f32x4*>(a.blend_h + o);
+            v = h + z * (v - h);
+          }
+          *reinterpret_cast<f32x4*>(outp + o) = v;
+        } else if (yb + yr < Hs) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (xb + e < Ws) {
+              const size_t oe = o + (size_t)(dil * e);
+              float u = fmaf(yv[r][e], sc, bi);
+              if (resp) u += resp[oe];
+              u = dv_act(u, a.act);
+              if (mulp) u *= mulp[oe];
+              if (a.blend_z) u = a.blend_h[oe] + a.blend_z[oe] * (u - a.blend_h[oe]);
+              outp[oe] = u;
+            }
+        }
+      }
+    }
+  }
+}
+
+// U = G g Gt per (cout, cin);  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+__global__ void pack_wino2d_weights_kernel(const float* __restrict__ w, float* __restrict__ wpk, int Cin, int Cout,
+                                           int nchunk, int nco) {
+  const size_t total = (size_t)nchunk * nco * 2 * 2 * 4 * 16;   // one thread per (chunk, cb, ks, nt, k, n)
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    size_t r = i;
+    const int n = (int)(r % 16); r /= 16;
+    const int k = (int)(r % 4); r /= 4;
+    const int nt = (int)(r % 2); r /= 2;
+    const int ks = (int)(r % 2); r /= 2;
+    const int cb = (int)(r % nco);
+    const int ch = (int)(r / nco);
+    const int co = cb * 32 + nt * 16 + n, ci = ch * 8 + ks * 4 + k;
+    float g[3][3];
+    for (int p = 0; p < 3; ++p)
+      for (int q = 0; q < 3; ++q) g[p][q] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * 9 + p * 3 + q] : 0.f;
+    float gg[4][3];
+    for (int q = 0; q < 3; ++q) {
+      gg[0][q] = g[0][q];
+      gg[1][q] = 0.5f * (g[0][q] + g[1][q] + g[2][q]);
+      gg[2][q] = 0.5f * (g[0][q] - g[1][q] + g[2][q]);
+      gg[3][q] = g[2][q];
+    }
+    float* dst = wpk + i * 16;
+    for (int p = 0; p < 4; ++p) {
+      dst[p * 4 + 0] = gg[p][0];
+      dst[p * 4 + 1] = 0.5f * (gg[p][0] + gg[p][1] + gg[p][2]);
+      dst[p * 4 + 2] = 0.5f * (gg[p][0] - gg[p][1] + gg[p][2]);
+      dst[p * 4 + 3] = gg[p][2];
+    }
+  }
+}
+
+inline int cdiv2(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace
+
+extern "C" size_t dv_conv2d_wino_packed_floats(int Cin, int Cout) {
+  if (Cin <= 0 || Cout <= 0) return 0;
+  return (size_t)cdiv2(Cin, 8) * cdiv2(Cout, 32) * w2::U_CHUNK;
+}
+
+extern "C" int dv_conv2d_wino_pack_weights_f32(const float* w, float* wpacked, int Cin, int Cout,
+                                               dv_stream_t stream) {
+  DV_REQUIRE_PTR(w);
+  DV_REQUIRE_PTR(wpacked);
+  DV_REQUIRE(Cin > 0 && Cout > 0, DV_ERR_SHAPE);
+  const int nchunk = cdiv2(Cin, 8), nco = cdiv2(Cout, 32);
+  const size_t total = (size_t)nchunk * nco * 2 * 2 * 4 * 16;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_wino2d_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wpacked, Cin,
+                     Cout, nchunk, nco);
+  return dv_launch_status();
+}
+
+namespace {
+int wino2d_launch(const float* const* inputs, const int* channels, int n_inputs, const float* wpacked,
+                  const float* ch_scale, const float* ch_bias, const float* residual, const float* mul,
+                  const float* blend_z, const float* blend_h, float* out, int B, int H, int W, int Cout, int dilation,
+                  int act, int gsplit, const float* residual2, const float* mul2, float* out2, dv_stream_t stream);
+}
+
+extern "C" int dv_conv2d_wino_dil_cat_f32(const float* const* inputs, const int* channels, int n_inputs,
+                                          const float* wpacked, const float* ch_scale, const float* ch_bias,
+                                          const float* residual, const float* mul, const float* blend_z,
+                                          const float* blend_h, float* out, int B, int H, int W, int Cout,
+                                          int dilation, int act, dv_stream_t stream) {
+  return wino2d_launch(inputs, channels, n_inputs, wpacked, ch_scale, ch_bias, residual, mul, blend_z, blend_h, out, B, H,
+                       W, Cout, dilation, act, 0, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int dv_conv2d_wino_cat_pair_f32(const float* const* inputs, const int* channels, int n_inputs,
+                                           const float* wpacked, const float* ch_scale, const float* ch_bias,
+                                           const float* residual1, const float* mul1, float* out1,
+                                           const float* residual2, const float* mul2, float* out2, int B, int H, int W,
+                                           int Cout1, int Cout2, int act, dv_stream_t stream) {
+  DV_REQUIRE_PTR(out2);
+  DV_REQUIRE(Cout1 > 0 && Cout2 > 0 && Cout1 % 32 == 0, DV_ERR_SHAPE);
+  DV_REQUIRE((!residual2 || dv_aligned16(residual2)) && (!mul2 || dv_aligned16(mul2)) && dv_aligned16(out2), DV_ERR_ALIGN);
+  return wino2d_launch(inputs, channels, n_inputs, wpacked, ch_scale, ch_bias, residual1, mul1, nullptr, nullptr, out1, B,
+                       H, W, Cout1 + Cout2, 1, act, Cout1, residual2, mul2, out2, stream);
+}
+
+namespace {
+int wino2d_launch(const float* const* inputs, const int* channels, int n_inputs, const float* wpacked,
+                  const float* ch_scale, const float* ch_bias, const float* residual, const float* mul,
+                  const float* blend_z, const float* blend_h, float* out, int B, int H, int W, int Cout, int dilation,
+                  int act, int gsplit, const float* residual2, const float* mul2, float* out2, dv_stream_t stream) {
+  DV_REQUIRE_PTR(inputs);
+  DV_REQUIRE(dilation >= 1 && dilation <= 16, DV_ERR_UNSUPPORTED);
+  DV_REQUIRE_PTR(channels);
+  DV_REQUIRE_PTR(wpacked);
+  DV_REQUIRE_PTR(out);
+  DV_REQUIRE(n_inputs >= 1 && n_inputs <= 4, DV_ERR_UNSUPPORTED);
+  DV_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0, DV_ERR_SHAPE);
+  DV_REQUIRE(act >= DV_ACT_NONE && act <= DV_ACT_TANH, DV_ERR_UNSUPPORTED);
+  DV_REQUIRE((blend_z == nullptr) == (blend_h == nullptr), DV_ERR_NULL);
+  DV_REQUIRE(dv_aligned16(wpacked), DV_ERR_ALIGN);
+  DV_REQUIRE((size_t)H * W * sizeof(float) <= 0x7fffffffull, DV_ERR_SHAPE);   // 31-bit byte offsets in a channel
+  Wino2dArgs a;
+  int cin = 0;
+  for (int i = 0; i < 4; ++i) {
+    if (i < n_inputs) {
+      DV_REQUIRE_PTR(inputs[i]);
+      DV_REQUIRE(channels[i] > 0, DV_ERR_SHAPE);
+      cin += channels[i];
+      a.src[i] = inputs[i];
+    } else {
+      a.src[i] = inputs[0];
+    }
+    a.cend[i] = cin;
+  }
+  a.wpk = wpacked; a.ch_scale = ch_scale; a.ch_bias = ch_bias; a.residual = residual; a.mul = mul;
+  a.blend_z = blend_z; a.blend_h = blend_h; a.out = out;
+  a.B = B; a.Cin = cin; a.H = H; a.W = W; a.Cout = Cout; a.act = act;
+  a.fast_ok = (W % 4 == 0) && dv_aligned16(out) && (!residual || dv_aligned16(residual)) &&
+              (!mul || dv_aligned16(mul)) && (!blend_z || (dv_aligned16(blend_z) && dv_aligned16(blend_h)));
+  a.dil = dilation;
+  a.gsplit = gsplit; a.residual2 = residual2; a.mul2 = mul2; a.out2 = out2;
+  a.ntx = cdiv2(cdiv2(W, dilation), w2::TW); a.nty = cdiv2(cdiv2(H, dilation), w2::TH); a.nco = cdiv2(Cout, 32);
+  const long long blocks = (long long)B * a.nco * a.nty * a.ntx * dilation * dilation;
+  if (blocks <= 0 || blocks > 0x7fffffffLL) return DV_ERR_SHAPE;
+  // vector staging needs whole 16-byte segments: W % 4 == 0 (then every channel plane is a multiple of 16 bytes), aligned
+  // sources, no sub-sampling
+  bool vec = dilation == 1 && W % 4 == 0;
+  for (int i = 0; i < n_inputs; ++i) vec = vec && dv_aligned16(inputs[i]);
+#ifdef DV_W2_NO_VEC
+  vec = false;
+#endif
+  // launches that leave most of the chip empty run the deep-prefetch variant
+  const bool deep = blocks < 512;
+  const dim3 grid((unsigned)blocks), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (deep && vec) hipLaunchKernelGGL((conv2d_wino_kernel<true, true>), grid, blk, 0, st, a);
+  else if (deep) hipLaunchKernelGGL((conv2d_wino_kernel<true, false>), grid, blk, 0, st, a);
+  else if (vec) hipLaunchKernelGGL((conv2d_wino_kernel<false, true>), grid, blk, 0, st, a);
+  else hipLaunchKernelGGL((conv2d_wino_kernel<false, false>), grid, blk, 0, st, a);
+  return dv_launch_status();
+}
+}  // namespace
+
+extern "C" int dv_conv2d_wino_cat_f32(const float* const* inputs, const int* channels, int n_inputs,
+                                      const float* wpacked, const float* ch_scale, const float* ch_bias,
+                                      const float* residual, const float* mul, const float* blend_z,
+                                      const float* blend_h, float* out, int B, int H, int W, int Cout, int act,
+                                      dv_stream_t stream) {
+  return dv_conv2d_wino_dil_cat_f32(inputs, channels, n_inputs, wpacked, ch_scale, ch_bias, residual, mul, blend_z,
+                                    blend_h, out, B, H, W, Cout, 1, act, stream);
+}

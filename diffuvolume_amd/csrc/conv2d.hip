@@ -108,12 +108,40 @@ __global__ __launch_bounds__(256, G::WPS) void conv2d_mfma_kernel(Conv2dArgs a) 
     for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const size_t plane = (size_t)a.H * a.W;
-  // sources of the (virtual) channel concatenation: batch-item base pointer and first channel of each
-  const float* sb[4];
-  sb[0] = a.in + (size_t)b * a.cend[0] * plane;
+  const int plane_bytes = (int)(plane * sizeof(float));      // < 2^31 (checked by the host)
+  const int nchunk = (a.Cin + KC - 1) / KC;
+  const int cbeg = __builtin_amdgcn_readfirstlane(a.kslices > 1 ? (nchunk * slice) / a.kslices : 0);
+  const int cend = __builtin_amdgcn_readfirstlane(a.kslices > 1 ? (nchunk * (slice + 1)) / a.kslices : nchunk);
+  // The channels of the (virtual) concatenation are fetched strictly in order, so the position in it is running scalar
+  // state -- byte address of the next channel plane, channels left in its source, a queue of the sources to come -- moved
+  // by selects (conv2d_wino.hip; looking the source up per channel cost two dependent kernarg loads, each closed by an
+  // s_waitcnt lgkmcnt(0), and a 64-bit multiply chain per channel).
+  auto sgpr64 = [](uint64_t v) __attribute__((always_inline)) {
+    return (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v) |
+           ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32);
+  };
+  constexpr int NEVER = 0x7fffffff;                 // an unused source slot: its counter never reaches zero
+  const int cw1 = a.cend[1] - a.cend[0], cw2 = a.cend[2] - a.cend[1], cw3 = a.cend[3] - a.cend[2];
+  uint64_t fb = sgpr64(reinterpret_cast<uint64_t>(a.in + (size_t)b * a.cend[0] * plane));
+  uint64_t nb1 = sgpr64(reinterpret_cast<uint64_t>(a.in_more[0] ? a.in_more[0] + (size_t)b * cw1 * plane : a.in));
+  uint64_t nb2 = sgpr64(reinterpret_cast<uint64_t>(a.in_more[1] ? a.in_more[1] + (size_t)b * cw2 * plane : a.in));
+  uint64_t nb3 = sgpr64(reinterpret_cast<uint64_t>(a.in_more[2] ? a.in_more[2] + (size_t)b * cw3 * plane : a.in));
+  int left = a.cend[0], nl1 = cw1 > 0 ? cw1 : NEVER, nl2 = cw2 > 0 ? cw2 : NEVER, nl3 = cw3 > 0 ? cw3 : NEVER;
+  int fc = cbeg * KC;                               // (a K-slice starts in the middle of the concatenation)
+  auto queue_up = [&]() __attribute__((always_inline)) {
+    fb = nb1; left = nl1;
+    nb1 = nb2; nl1 = nl2;
+    nb2 = nb3; nl2 = nl3;
+    nl3 = NEVER;
+  };
+  {
+    int skip = fc;
 #pragma unroll
-  for (int k = 1; k < 4; ++k)
-    sb[k] = a.in_more[k - 1] ? a.in_more[k - 1] + (size_t)b * (a.cend[k] - a.cend[k - 1]) * plane : a.in;
+    for (int k = 0; k < 3; ++k)
+      if (skip >= left) { skip -= left; queue_up(); }
+    fb += (uint64_t)(unsigned)skip * (uint64_t)(unsigned)plane_bytes;
+    left -= skip;
+  }
 
   // ---- staging plan: each thread owns NS positions of the staged rows (same for every channel) ----
   constexpr int NS = (G::RMAX * G::CMAX + 255) / 256;
@@ -128,29 +156,26 @@ __global__ __launch_bounds__(256, G::WPS) void conv2d_mfma_kernel(Conv2dArgs a) 
     const bool ok = r < R * C && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
     sob[i] = ok ? (unsigned)(gy * a.W + gx) * 4u : 0x80000000u;
   }
-  const int plane_bytes = (int)(plane * sizeof(float));      // < 2^31 (checked by the host)
   float vin[KC][NS];
   f32x4 vw[NWQ];
-  const int nchunk = (a.Cin + KC - 1) / KC;
   auto fetch = [&](int c) {
 #pragma unroll
     for (int cl = 0; cl < KC; ++cl) {
-      const int ch = c * KC + cl;
-      const int cc = ch < a.Cin ? ch : 0;                                   // wave-uniform source selection
-      const int k = (cc >= a.cend[0]) + (cc >= a.cend[1]) + (cc >= a.cend[2]);
-      const float* base = k == 0 ? sb[0] : (k == 1 ? sb[1] : (k == 2 ? sb[2] : sb[3]));
-      const int c_in_src = cc - (k == 0 ? 0 : a.cend[k - 1]);
       // buffer loads, one descriptor per channel built on the scalar unit: zero padding and the channel tail (zero
       // records) come out of the hardware range check, the lane address is a 32-bit offset
-      const uint64_t ba = reinterpret_cast<uint64_t>(base + (size_t)c_in_src * plane);
-      const uint64_t bu = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ba) |
-                          ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ba >> 32)) << 32);
-      const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(bu), 0,
-                                                        __builtin_amdgcn_readfirstlane(ch < a.Cin ? plane_bytes : 0),
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(fb), 0, fc < a.Cin ? plane_bytes : 0,
                                                         0x00020000);
 #pragma unroll
       for (int i = 0; i < NS; ++i)
         vin[cl][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)sob[i], 0, 0));
+      ++fc;
+      --left;
+      fb += (uint64_t)(unsigned)plane_bytes;
+      const bool sw = left == 0;                    // source exhausted: the queue moves up
+      fb = sw ? nb1 : fb;   left = sw ? nl1 : left;
+      nb1 = sw ? nb2 : nb1; nl1 = sw ? nl2 : nl1;
+      nb2 = sw ? nb3 : nb2; nl2 = sw ? nl3 : nl2;
+      nl3 = sw ? NEVER : nl3;
     }
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpk + ((size_t)c * a.nco + tc) * G::W_FLOATS);
 #pragma unroll
@@ -206,8 +231,6 @@ __global__ __launch_bounds__(256, G::WPS) void conv2d_mfma_kernel(Conv2dArgs a) 
     }
   };
 
-  const int cbeg = __builtin_amdgcn_readfirstlane(a.kslices > 1 ? (nchunk * slice) / a.kslices : 0);
-  const int cend = __builtin_amdgcn_readfirstlane(a.kslices > 1 ? (nchunk * (slice + 1)) / a.kslices : nchunk);
   fetch(cbeg);
   for (int c = cbeg; c < cend; ++c) {
     __syncthreads();

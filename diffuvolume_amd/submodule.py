@@ -602,7 +602,7 @@ class Conv2dPlan:
         self.scale, self.shift = _fold_bn(bn, bias, self.cout, w.device, eps)
 
     WINO_MIN_BLOCKS = 128
-    WINO_MAX_DILATION = 4       # measured at 1248x384: d=2 -13 %, d=4 -8.5 %, d=8 +6 %, d=16 +47 % (the gathers spread over too many sectors)
+    WINO_MAX_DILATION = 8       # measured at 1248x384 (tools/ab_wino2d_dil.py): d=2 -27 %, d=4 -19 %, d=8 -11..17 %, d=16 +41..57 % (the gathers spread over too many sectors)
     KSPLIT = True               # K-split the launches that are too small to fill the chip (A/B switch for tools/)
 
     def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, mul: Optional[torch.Tensor] = None,

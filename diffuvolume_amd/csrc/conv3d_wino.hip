@@ -386,41 +386,70 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
 #pragma unroll
       for (int r = 0; r < 4; ++r) rv[r] = *reinterpret_cast<const f32x4*>(a.residual + cbase + (size_t)r * a.W);
     }
+    // Output transform on packed fp32: the two tile rows of a tile column are elements (2h, 2h+1) of every accumulator,
+    // i.e. an aligned register pair, and At M A is the same arithmetic for both -- 12 v_pk_add_f32 per (column pair, n)
+    // instead of 24 + 24 scalar adds (the epilogue is pure vector-ALU work on the pipe the MFMAs of the CU's other block
+    // need: skipping it altogether measured -10.7 % on the 32->32 layer, profiles/r03_wino3d_epilogue.txt).
+    f32x2 yq2[2][2][2];                    // [tile column h][output row of the tile rr][output column of the tile] over (tr 0, tr 1)
 #pragma unroll
-    for (int tr = 0; tr < 2; ++tr) {       // tile row
-      float yv[2][4];                      // two output rows x 4 x
+    for (int h = 0; h < 2; ++h) {
+      f32x2 s0[4], s1[4];
 #pragma unroll
-      for (int tcx = 0; tcx < 2; ++tcx) {  // tile column 2kq + tcx = accumulator element i = tr + 2*tcx
-        const int i = tr + 2 * tcx;
-        float s0[4], s1[4];
-#pragma unroll
-        for (int px = 0; px < 4; ++px) {
-          const float m0 = acc[mt][px][n][i], m1 = acc[mt][4 + px][n][i], m2 = acc[mt][8 + px][n][i], m3 = acc[mt][12 + px][n][i];
-          s0[px] = m0 + m1 + m2;
-          s1[px] = m1 - m2 - m3;
-        }
-        yv[0][2 * tcx] = s0[0] + s0[1] + s0[2];
-        yv[0][2 * tcx + 1] = s0[1] - s0[2] - s0[3];
-        yv[1][2 * tcx] = s1[0] + s1[1] + s1[2];
-        yv[1][2 * tcx + 1] = s1[1] - s1[2] - s1[3];
+      for (int px = 0; px < 4; ++px) {
+        const f32x2 m0 = {acc[mt][px][n][2 * h], acc[mt][px][n][2 * h + 1]};
+        const f32x2 m1 = {acc[mt][4 + px][n][2 * h], acc[mt][4 + px][n][2 * h + 1]};
+        const f32x2 m2 = {acc[mt][8 + px][n][2 * h], acc[mt][8 + px][n][2 * h + 1]};
+        const f32x2 m3 = {acc[mt][12 + px][n][2 * h], acc[mt][12 + px][n][2 * h + 1]};
+        s0[px] = m0 + m1 + m2;
+        s1[px] = m1 - m2 - m3;
       }
+      yq2[h][0][0] = s0[0] + s0[1] + s0[2];
+      yq2[h][0][1] = s0[1] - s0[2] - s0[3];
+      yq2[h][1][0] = s1[0] + s1[1] + s1[2];
+      yq2[h][1][1] = s1[1] - s1[2] - s1[3];
+    }
+    // The uniform decisions (fast path, activation kind, residual) are taken ONCE per (plane, n): taken per element they
+    // were a branch and four v_cndmask per stored row.
+    auto rows = [&](auto relu_c, auto res_c) __attribute__((always_inline)) {
+      constexpr bool RELU = decltype(relu_c)::value, RES = decltype(res_c)::value;
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int yr = 2 * tr + r;
-        const size_t o = cbase + (size_t)yr * a.W;
-        if (fast) {
+      for (int tr = 0; tr < 2; ++tr) {     // tile row
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int yr = 2 * tr + r;
+          const float y4[4] = {yq2[0][r][0][tr], yq2[0][r][1][tr], yq2[1][r][0][tr], yq2[1][r][1][tr]};
           f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaf(yv[r][e], sc, bi);
-          if (a.residual) v += rv[yr];
+          for (int e = 0; e < 4; ++e) v[e] = fmaf(y4[e], sc, bi);
+          if (RES) v += rv[yr];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = mish ? dv_act(v[e], DV_ACT_MISH) : fmaxf(v[e], v[e] * slope);
-          *reinterpret_cast<f32x4*>(a.out + o) = v;
-        } else if (y0 + yq + yr < a.H) {
+          for (int e = 0; e < 4; ++e) {
+            if (RELU) v[e] = v[e] < 0.f ? 0.f : v[e];                      // (NaN stays NaN, as torch.relu)
+            else v[e] = mish ? dv_act(v[e], DV_ACT_MISH) : fmaxf(v[e], v[e] * slope);
+          }
+          *reinterpret_cast<f32x4*>(a.out + cbase + (size_t)yr * a.W) = v;
+        }
+      }
+    };
+    if (fast) {
+      const bool relu = a.act == DV_ACT_RELU;
+      if (relu && a.residual) rows(std::true_type{}, std::true_type{});
+      else if (relu) rows(std::true_type{}, std::false_type{});
+      else if (a.residual) rows(std::false_type{}, std::true_type{});
+      else rows(std::false_type{}, std::false_type{});
+    } else {
+#pragma unroll
+      for (int tr = 0; tr < 2; ++tr) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int yr = 2 * tr + r;
+          if (y0 + yq + yr >= a.H) continue;
+          const size_t o = cbase + (size_t)yr * a.W;
+          const float y4[4] = {yq2[0][r][0][tr], yq2[0][r][1][tr], yq2[1][r][0][tr], yq2[1][r][1][tr]};
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (xb + e < a.W) {
-              float u = fmaf(yv[r][e], sc, bi);
+              float u = fmaf(y4[e], sc, bi);
               if (a.residual) u += a.residual[o + e];
               a.out[o + e] = dv_act(u, a.act);
             }

@@ -112,13 +112,9 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
   const int b = t / a.ntz;
   const int x0 = tx * TW, y0 = ty * TH, z0 = tz * TD, co0 = tc * 32;
 
+  // (not zeroed: the first chunk's MFMAs take the inline constant 0 as their C operand -- 128 v_mov less per block, on
+  // the issue pipe the MFMAs of the CU's other block need)
   f32x4 acc[MTW][16][NT];
-#pragma unroll
-  for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-    for (int p = 0; p < 16; ++p)
-#pragma unroll
-      for (int n = 0; n < NT; ++n) acc[mt][p][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const size_t plane = (size_t)a.H * a.W;
   const size_t vol = (size_t)a.D * plane;
@@ -245,7 +241,8 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
   commit_raw(raw_s);
   if (wg::BF || KC < a.Cin) fetch_raw(KC);
   // one chunk: `vin` holds the raw brick of chunk c0+KC on entry and that of chunk c0+2*KC on exit
-  auto chunk = [&](int c0, int cur) __attribute__((always_inline)) {
+  auto chunk = [&](int c0, int cur, auto first_c) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_c)::value;
     // this chunk's weights (DMA, issued at the start of the previous chunk) have to be in LDS; the raw loads issued
     // after them (KC*NS per thread, for chunk c0+KC) may stay in flight.  After the barrier every wave is done with
     // the other pair of buffers and this chunk's raw brick is complete.
@@ -342,8 +339,9 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
         for (int n = 0; n < NT; ++n)
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            acc[mt][p4 * 4 + e][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[mt][kd & 1][p4][e >> 1][e & 1], bq[g & 1][n][e],
-                                                                          acc[mt][p4 * 4 + e][n], 0, 0, 0);
+            acc[mt][p4 * 4 + e][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                vp[mt][kd & 1][p4][e >> 1][e & 1], bq[g & 1][n][e],
+                FIRST && kd == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mt][p4 * 4 + e][n], 0, 0, 0);
       if (p4 == 1 && kd < 2) transform((kd + 1) & 1);
     }
     const int dr = cur ? -4 * RAW_FLOATS : 4 * RAW_FLOATS, du = cur ? -4 * U_CHUNK : 4 * U_CHUNK;   // scalar
@@ -355,9 +353,10 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
     for (int i = 0; i < NS; ++i) wo[i] -= dr;
   };
   {
-    int cur = 0;
+    chunk(0, 0, std::true_type{});
+    int cur = 1;
 #pragma unroll 1
-    for (int c0 = 0; c0 < a.Cin; c0 += KC, cur ^= 1) chunk(c0, cur);
+    for (int c0 = KC; c0 < a.Cin; c0 += KC, cur ^= 1) chunk(c0, cur, std::false_type{});
   }
 
   if (wg::BF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus weight DMA of the last chunk
@@ -418,14 +417,15 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
         for (int r = 0; r < 2; ++r) {
           const int yr = 2 * tr + r;
           const float y4[4] = {yq2[0][r][0][tr], yq2[0][r][1][tr], yq2[1][r][0][tr], yq2[1][r][1][tr]};
-          f32x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaf(y4[e], sc, bi);
+          f32x4 v = (f32x4){y4[0], y4[1], y4[2], y4[3]} * sc + bi;          // (contracted to fma; packed by the compiler)
           if (RES) v += rv[yr];
+          if (RELU) {
+            // max(v, v*0): NaN stays NaN as in torch.relu; two instructions per element and no VCC round trip (a compare
+            // + select costs two wait states per element on gfx950)
+            v = __builtin_elementwise_max(v, v * 0.f);
+          } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (RELU) v[e] = v[e] < 0.f ? 0.f : v[e];                      // (NaN stays NaN, as torch.relu)
-            else v[e] = mish ? dv_act(v[e], DV_ACT_MISH) : fmaxf(v[e], v[e] * slope);
+            for (int e = 0; e < 4; ++e) v[e] = mish ? dv_act(v[e], DV_ACT_MISH) : fmaxf(v[e], v[e] * slope);
           }
           *reinterpret_cast<f32x4*>(a.out + cbase + (size_t)yr * a.W) = v;
         }

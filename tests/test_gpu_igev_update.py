@@ -303,3 +303,34 @@ def test_deconv2d_k4s2_as_parity_convolutions(cfg):
     out = plan(dev(x))
     assert tuple(out.shape) == (b, cout, 2 * h, 2 * w)
     assert rel_err(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("chans", [(128, 127, 1, 128), (1, 1, 1, 1), (7, 1), (9, 8, 7, 6), (1, 30, 1), (3,), (8, 8, 8, 8),
+                                   (5, 1, 1, 9)])
+@pytest.mark.parametrize("kernel", ["wino", "direct", "ksplit"])
+def test_conv2d_source_queue_edge_cases(chans, kernel, monkeypatch):
+    """The position in the virtual concatenation is running scalar state in the 2-D kernels (address of the next channel
+    plane, channels left in the source, a queue of the sources to come; conv2d_wino.hip / conv2d.hip).  Its corner cases:
+    one-channel sources (IGEV hands the GRU `[h 128 | motion 127 | disp 1 | interp 128]`, KITTI15/core/update.py:126-142),
+    several source switches inside one 8-channel chunk, four sources, a channel count that is not a multiple of the chunk,
+    a second batch item (every source has its own batch stride), and K-slices that start in the middle of a source."""
+    from diffuvolume_amd import _lib
+    cin, cout = sum(chans), 32
+    b, h, w = (2, 24, 40) if kernel != "ksplit" else (1, 12, 20)
+    g = _gen(311, f"{chans}{kernel}")
+    xs = [torch.randn(b, c, h, w, generator=g) for c in chans]
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    ref = torch.tanh(F.conv2d(torch.cat(xs, 1).double(), wt.double(), bias.double(), 1, 1)).float()
+    monkeypatch.setattr(S.Conv2dPlan, "WINO_MIN_BLOCKS", 0)
+    monkeypatch.setattr(S.Conv2dPlan, "KSPLIT", kernel == "ksplit")
+    plan = S.Conv2dPlan(dev(wt), None, act=S.ACT_TANH, bias=dev(bias))
+    if kernel != "wino":
+        plan.wino_packed = None
+    if kernel == "ksplit" and cin >= 16:
+        assert _lib.load().dv_conv2d_auto_kslices(b, cin, h, w, cout, 3, 1) > 1
+    out = plan([dev(t) for t in xs])
+    assert float((out.cpu() - ref).abs().max()) <= 3e-6 * max(1.0, float(ref.abs().max()))
+    # the same through one materialised tensor, and with the sources as views into it (unequal base alignment)
+    cat = dev(torch.cat(xs, 1))
+    assert torch.equal(plan(cat), out)

@@ -293,9 +293,10 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
   const bool fast = a.fast_ok && co0 + kCOUT <= a.Cout;
   // ReLU / LeakyReLU / identity are max(v, slope * v) with slope 0 / 0.01 / 1; Mish has its own variant.
   const float slope = a.act == DV_ACT_RELU ? 0.f : (a.act == DV_ACT_LEAKY ? 0.01f : 1.f);
-  auto epilogue_fast = [&](auto mishc, auto resc) __attribute__((always_inline)) {
+  auto epilogue_fast = [&](auto mishc, auto resc, auto reluc) __attribute__((always_inline)) {
     constexpr bool MISH = decltype(mishc)::value;
     constexpr bool RES = decltype(resc)::value;
+    constexpr bool RELU = decltype(reluc)::value;
     unsigned loff[kNT][kMTX];
     float sc[kNT], bi[kNT];
     bool lo_ok[kMTX], hi_ok[kMTX];
@@ -342,17 +343,27 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
 #pragma unroll
       for (int m = 0; m < kMTX; ++m) {
         const f32x4 e0 = acc[m][k << 1][n], e1 = acc[m][(k << 1) | 1][n];
-        f32x4 lo = {e0[0], e1[0], e0[1], e1[1]}, hi = {e0[2], e1[2], e0[3], e1[3]};
-        lo = lo * sc[n] + bi[n];
-        hi = hi * sc[n] + bi[n];
+        // (scalar fmas straight into the interleaved order: the packed form needs eight moves to pair the two x
+        // parities first; while this block is in its epilogue its SIMDs run on the other block's waves alone, so the
+        // LENGTH of the epilogue in vector instructions is what counts, profiles/r03_wino3d_epilogue.txt)
+        f32x4 lo, hi;
+        lo[0] = fmaf(e0[0], sc[n], bi[n]); lo[1] = fmaf(e1[0], sc[n], bi[n]);
+        lo[2] = fmaf(e0[1], sc[n], bi[n]); lo[3] = fmaf(e1[1], sc[n], bi[n]);
+        hi[0] = fmaf(e0[2], sc[n], bi[n]); hi[1] = fmaf(e1[2], sc[n], bi[n]);
+        hi[2] = fmaf(e0[3], sc[n], bi[n]); hi[3] = fmaf(e1[3], sc[n], bi[n]);
         if (RES) {
           lo += rv[q % RD][m][0];
           hi += rv[q % RD][m][1];
         }
+        if (RELU) {                          // max(v, v*0): NaN stays NaN; packed multiply + one max per element
+          lo = __builtin_elementwise_max(lo, lo * 0.f);
+          hi = __builtin_elementwise_max(hi, hi * 0.f);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          lo[r] = MISH ? dv_act(lo[r], DV_ACT_MISH) : fmaxf(lo[r], lo[r] * slope);
-          hi[r] = MISH ? dv_act(hi[r], DV_ACT_MISH) : fmaxf(hi[r], hi[r] * slope);
+          for (int r = 0; r < 4; ++r) {
+            lo[r] = MISH ? dv_act(lo[r], DV_ACT_MISH) : fmaxf(lo[r], lo[r] * slope);
+            hi[r] = MISH ? dv_act(hi[r], DV_ACT_MISH) : fmaxf(hi[r], hi[r] * slope);
+          }
         }
         if (lo_ok[m]) *reinterpret_cast<f32x4*>(orow + loff[n][m]) = lo;
         if (hi_ok[m]) *reinterpret_cast<f32x4*>(orow + loff[n][m] + 16) = hi;
@@ -362,11 +373,14 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
   };
   if (fast) {
     if (a.act == DV_ACT_MISH) {
-      if (a.residual) epilogue_fast(std::true_type{}, std::true_type{});
-      else epilogue_fast(std::true_type{}, std::false_type{});
+      if (a.residual) epilogue_fast(std::true_type{}, std::true_type{}, std::false_type{});
+      else epilogue_fast(std::true_type{}, std::false_type{}, std::false_type{});
+    } else if (a.act == DV_ACT_RELU) {
+      if (a.residual) epilogue_fast(std::false_type{}, std::true_type{}, std::true_type{});
+      else epilogue_fast(std::false_type{}, std::false_type{}, std::true_type{});
     } else {
-      if (a.residual) epilogue_fast(std::false_type{}, std::true_type{});
-      else epilogue_fast(std::false_type{}, std::false_type{});
+      if (a.residual) epilogue_fast(std::false_type{}, std::true_type{}, std::false_type{});
+      else epilogue_fast(std::false_type{}, std::false_type{}, std::false_type{});
     }
   }
   auto epilogue = [&](auto actc) __attribute__((always_inline)) {

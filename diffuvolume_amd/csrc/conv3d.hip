@@ -228,9 +228,10 @@ __global__ __launch_bounds__(256, G::WPS) void conv3d_mfma_kernel(ConvArgs a) {
   const bool fast = a.fast_ok && co0 + G::COUT <= a.Cout && x0 + G::TW <= a.Wo && y0 + G::TH <= a.Ho &&
                     z0 + G::TD <= a.Do;
   const float slope = a.act == DV_ACT_RELU ? 0.f : (a.act == DV_ACT_LEAKY ? 0.01f : 1.f);
-  auto epilogue_fast = [&](auto mishc, auto resc) __attribute__((always_inline)) {
+  auto epilogue_fast = [&](auto mishc, auto resc, auto reluc) __attribute__((always_inline)) {
     constexpr bool MISH = decltype(mishc)::value;
     constexpr bool RES = decltype(resc)::value;
+    constexpr bool RELU = decltype(reluc)::value;
     unsigned loff[G::NT][G::MTX];
     float sc[G::NT], bi[G::NT];
 #pragma unroll
@@ -272,8 +273,12 @@ __global__ __launch_bounds__(256, G::WPS) void conv3d_mfma_kernel(ConvArgs a) {
         for (int xt = 0; xt < G::MTX; ++xt) {
           f32x4 v = acc[r * G::MTX + xt][n] * sc[n] + bi[n];
           if (RES) v += rv[r % RD][n][xt];
+          if (RELU) {                        // max(v, v*0): NaN stays NaN; packed multiply + one max per element
+            v = __builtin_elementwise_max(v, v * 0.f);
+          } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = MISH ? dv_act(v[e], DV_ACT_MISH) : fmaxf(v[e], v[e] * slope);
+            for (int e = 0; e < 4; ++e) v[e] = MISH ? dv_act(v[e], DV_ACT_MISH) : fmaxf(v[e], v[e] * slope);
+          }
           *reinterpret_cast<f32x4*>(orow + loff[n][xt]) = v;
         }
       __builtin_amdgcn_sched_barrier(0);
@@ -281,11 +286,14 @@ __global__ __launch_bounds__(256, G::WPS) void conv3d_mfma_kernel(ConvArgs a) {
   };
   if (fast) {
     if (a.act == DV_ACT_MISH) {
-      if (a.residual) epilogue_fast(std::true_type{}, std::true_type{});
-      else epilogue_fast(std::true_type{}, std::false_type{});
+      if (a.residual) epilogue_fast(std::true_type{}, std::true_type{}, std::false_type{});
+      else epilogue_fast(std::true_type{}, std::false_type{}, std::false_type{});
+    } else if (a.act == DV_ACT_RELU) {
+      if (a.residual) epilogue_fast(std::false_type{}, std::true_type{}, std::true_type{});
+      else epilogue_fast(std::false_type{}, std::false_type{}, std::true_type{});
     } else {
-      if (a.residual) epilogue_fast(std::false_type{}, std::true_type{});
-      else epilogue_fast(std::false_type{}, std::false_type{});
+      if (a.residual) epilogue_fast(std::false_type{}, std::true_type{}, std::false_type{});
+      else epilogue_fast(std::false_type{}, std::false_type{}, std::false_type{});
     }
     return;
   }

@@ -319,32 +319,64 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
     const float sc = a.ch_scale ? a.ch_scale[co] : 1.f;
     const float bi = a.ch_bias ? a.ch_bias[co] : 0.f;
     const size_t cbase = (((size_t)b * coutg + (co - cog0)) * a.H + (ry + dil * yb)) * a.W + (rx + dil * xb);
+    // At M A on packed fp32 over the two tile rows (elements 2h, 2h+1 of every accumulator are an aligned register pair;
+    // conv3d_wino.hip), then the rows: the plain ReLU / identity layers (feature CNNs, refinement stack, motion encoder)
+    // take a path whose uniform decisions are made once, the gate epilogues (sigmoid / tanh, `mul`, GRU blend) the
+    // general one.  An epilogue instruction is not hidden by the other block's MFMAs -- they share the issue pipe.
+    f32x2 yq2[2][2][2];                    // [tile column h][row of the tile][column of the tile] over (tile row 0, 1)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x2 s0[4], s1[4];
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+        const f32x2 m0 = {acc[px][n][2 * h], acc[px][n][2 * h + 1]};
+        const f32x2 m1 = {acc[4 + px][n][2 * h], acc[4 + px][n][2 * h + 1]};
+        const f32x2 m2 = {acc[8 + px][n][2 * h], acc[8 + px][n][2 * h + 1]};
+        const f32x2 m3 = {acc[12 + px][n][2 * h], acc[12 + px][n][2 * h + 1]};
+        s0[px] = m0 + m1 + m2;
+        s1[px] = m1 - m2 - m3;
+      }
+      yq2[h][0][0] = s0[0] + s0[1] + s0[2];
+      yq2[h][0][1] = s0[1] - s0[2] - s0[3];
+      yq2[h][1][0] = s1[0] + s1[1] + s1[2];
+      yq2[h][1][1] = s1[1] - s1[2] - s1[3];
+    }
+    auto plain_rows = [&](auto relu_c, auto res_c) __attribute__((always_inline)) {
+      constexpr bool RELU = decltype(relu_c)::value, RES = decltype(res_c)::value;
+#pragma unroll
+      for (int tr = 0; tr < 2; ++tr) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const size_t o = cbase + (size_t)(2 * tr + r) * a.W;
+          f32x4 v = (f32x4){yq2[0][r][0][tr], yq2[0][r][1][tr], yq2[1][r][0][tr], yq2[1][r][1][tr]} * sc + bi;
+          if (RES) v += *reinterpret_cast<const f32x4*>(resp + o);
+          if (RELU) v = __builtin_elementwise_max(v, v * 0.f);      // NaN stays NaN, as torch.relu
+          *reinterpret_cast<f32x4*>(outp + o) = v;
+        }
+      }
+    };
+    const bool plain = fast && !mulp && !a.blend_z && (a.act == DV_ACT_RELU || a.act == DV_ACT_NONE);
+    if (plain) {
+      if (a.act == DV_ACT_RELU) {
+        if (resp) plain_rows(std::true_type{}, std::true_type{});
+        else plain_rows(std::true_type{}, std::false_type{});
+      } else {
+        if (resp) plain_rows(std::false_type{}, std::true_type{});
+        else plain_rows(std::false_type{}, std::false_type{});
+      }
+      continue;
+    }
 #pragma unroll
     for (int tr = 0; tr < 2; ++tr) {
-      float yv[2][4];
-#pragma unroll
-      for (int tcx = 0; tcx < 2; ++tcx) {
-        const int i = tr + 2 * tcx;
-        float s0[4], s1[4];
-#pragma unroll
-        for (int px = 0; px < 4; ++px) {
-          const float m0 = acc[px][n][i], m1 = acc[4 + px][n][i], m2 = acc[8 + px][n][i], m3 = acc[12 + px][n][i];
-          s0[px] = m0 + m1 + m2;
-          s1[px] = m1 - m2 - m3;
-        }
-        yv[0][2 * tcx] = s0[0] + s0[1] + s0[2];
-        yv[0][2 * tcx + 1] = s0[1] - s0[2] - s0[3];
-        yv[1][2 * tcx] = s1[0] + s1[1] + s1[2];
-        yv[1][2 * tcx + 1] = s1[1] - s1[2] - s1[3];
-      }
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int yr = 2 * tr + r;
         const size_t o = cbase + (size_t)(dil * yr) * a.W;
+        const float y4[4] = {yq2[0][r][0][tr], yq2[0][r][1][tr], yq2[1][r][0][tr], yq2[1][r][1][tr]};
         if (fast) {
           f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaf(yv[r][e], sc, bi);
+          for (int e = 0; e < 4; ++e) v[e] = fmaf(y4[e], sc, bi);
           if (resp) v += *reinterpret_cast<const f32x4*>(resp + o);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = gen ? dv_act(v[e], a.act) : fmaxf(v[e], v[e] * slope);
@@ -360,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
           for (int e = 0; e < 4; ++e)
             if (xb + e < Ws) {
               const size_t oe = o + (size_t)(dil * e);
-              float u = fmaf(yv[r][e], sc, bi);
+              float u = fmaf(y4[e], sc, bi);
               if (resp) u += resp[oe];
               u = dv_act(u, a.act);
               if (mulp) u *= mulp[oe];

@@ -87,11 +87,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
   const int Hs = (a.H - ry + dil - 1) / dil, Ws = (a.W - rx + dil - 1) / dil;   // size of this sub-image
   if (y0 >= Hs || x0 >= Ws) return;                              // (the tile grid is that of the largest sub-image)
 
+  // (not zeroed: the first chunk's first k-step takes the inline constant 0 as its C operand, conv3d_wino.hip)
   f32x4 acc[16][NT];
-#pragma unroll
-  for (int p = 0; p < 16; ++p)
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[p][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const size_t plane = (size_t)a.H * a.W;
   const int plane_bytes = (int)(plane * sizeof(float));      // < 2^31 (checked by the host)
@@ -202,7 +199,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
 
   // one chunk.  `vin` holds the raw brick of chunk c0+KC on entry and is refilled for chunk c0+2*KC (deep: c0+3*KC);
   // ub = LDS weight image of this chunk, unxt = target of the DMA issued in this chunk (chunk c0+KC, deep: c0+2*KC)
-  auto chunk = [&](int c0, int cur, const float* ub, float* unxt, RawSet& vin) __attribute__((always_inline)) {
+  auto chunk = [&](int c0, int cur, const float* ub, float* unxt, RawSet& vin, auto first_c) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_c)::value;
     // this chunk's weights (DMA) have to be in LDS; the loads issued after that DMA may stay in flight: the raw loads
     // of the next chunk (shallow), or raw + DMA + raw of the next two (deep)
     // The chunk body has NO branch: the staging of the chunks to come is issued whether or not they exist (a channel
@@ -275,26 +273,30 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
       for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          acc[p4 * 4 + e][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[ks & 1][p4][e >> 1][e & 1], bq[g & 1][n][e],
-                                                                    acc[p4 * 4 + e][n], 0, 0, 0);
+          acc[p4 * 4 + e][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+              vp[ks & 1][p4][e >> 1][e & 1], bq[g & 1][n][e],
+              FIRST && ks == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[p4 * 4 + e][n], 0, 0, 0);
       if (p4 == 1 && ks + 1 < NKS) transform((ks + 1) & 1);
     }
   };
   if (DEEP) {
     // weight ring slot of chunk k = k % 3; raw LDS buffer k & 1; register set of chunk k+1 alternates B, A, B, ...
     int iu = 0;
-#pragma unroll 1
-    for (int c0 = 0; c0 < n_in; c0 += 2 * KC) {
+    auto pair = [&](int c0, auto first_c) __attribute__((always_inline)) {
       const int iu1 = iu == 2 ? 0 : iu + 1, iu2 = iu1 == 2 ? 0 : iu1 + 1;
-      chunk(c0, 0, u_s + iu * U_CHUNK, u_s + iu2 * U_CHUNK, vinB);
-      if (c0 + KC < n_in) chunk(c0 + KC, 1, u_s + iu1 * U_CHUNK, u_s + iu * U_CHUNK, vinA);
+      chunk(c0, 0, u_s + iu * U_CHUNK, u_s + iu2 * U_CHUNK, vinB, first_c);
+      if (c0 + KC < n_in) chunk(c0 + KC, 1, u_s + iu1 * U_CHUNK, u_s + iu * U_CHUNK, vinA, std::false_type{});
       iu = iu2;
-    }
-  } else {
-    int cur = 0;
+    };
+    pair(0, std::true_type{});
 #pragma unroll 1
-    for (int c0 = 0; c0 < n_in; c0 += KC, cur ^= 1)
-      chunk(c0, cur, u_s + cur * U_CHUNK, u_s + (cur ^ 1) * U_CHUNK, vinA);
+    for (int c0 = 2 * KC; c0 < n_in; c0 += 2 * KC) pair(c0, std::false_type{});
+  } else {
+    chunk(0, 0, u_s, u_s + U_CHUNK, vinA, std::true_type{});
+    int cur = 1;
+#pragma unroll 1
+    for (int c0 = KC; c0 < n_in; c0 += KC, cur ^= 1)
+      chunk(c0, cur, u_s + cur * U_CHUNK, u_s + (cur ^ 1) * U_CHUNK, vinA, std::false_type{});
   }
 
   // the last chunks' surplus weight DMA must have landed before this block's LDS can be given to another one

@@ -357,7 +357,38 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
         }
       }
     };
-    const bool plain = fast && !mulp && !a.blend_z && (a.act == DV_ACT_RELU || a.act == DV_ACT_NONE);
+    // the same for a dilated layer (a tile of one sub-sampled image: outputs `dil` apart, scalar stores) when the tile
+    // lies inside its sub-image -- the general path below tests every element
+    auto plain_rows_dil = [&](auto relu_c, auto res_c) __attribute__((always_inline)) {
+      constexpr bool RELU = decltype(relu_c)::value, RES = decltype(res_c)::value;
+#pragma unroll
+      for (int tr = 0; tr < 2; ++tr) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const size_t o = cbase + (size_t)(dil * (2 * tr + r)) * a.W;
+          f32x4 v = (f32x4){yq2[0][r][0][tr], yq2[0][r][1][tr], yq2[1][r][0][tr], yq2[1][r][1][tr]} * sc + bi;
+          if (RES) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += resp[o + (size_t)(dil * e)];
+          }
+          if (RELU) v = __builtin_elementwise_max(v, v * 0.f);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) outp[o + (size_t)(dil * e)] = v[e];
+        }
+      }
+    };
+    const bool plain_act = !mulp && !a.blend_z && (a.act == DV_ACT_RELU || a.act == DV_ACT_NONE);
+    if (plain_act && dil > 1 && x0 + TW <= Ws && yb + 4 <= Hs) {
+      if (a.act == DV_ACT_RELU) {
+        if (resp) plain_rows_dil(std::true_type{}, std::true_type{});
+        else plain_rows_dil(std::true_type{}, std::false_type{});
+      } else {
+        if (resp) plain_rows_dil(std::false_type{}, std::true_type{});
+        else plain_rows_dil(std::false_type{}, std::false_type{});
+      }
+      continue;
+    }
+    const bool plain = fast && plain_act;
     if (plain) {
       if (a.act == DV_ACT_RELU) {
         if (resp) plain_rows(std::true_type{}, std::true_type{});

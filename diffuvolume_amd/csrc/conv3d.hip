@@ -17,6 +17,8 @@
 
 #include <type_traits>
 
+#include <cstdlib>
+
 #include "dv_common.h"
 
 namespace {
@@ -462,7 +464,200 @@ __global__ __launch_bounds__(256, 4) void conv3d_c1_kernel(ConvArgs a) {
   }
 }
 
+
+// K4z: the single-channel head again, marching along z.  A block owns a 16 x 64 in-plane tile and a segment of ZS output
+// planes; it streams the input planes z0-1 .. z0+ZS of all channels through LDS ONE plane at a time, and every plane
+// feeds three rotating accumulator sets (the outputs one plane below, at, and above it), so a voxel is fetched once per
+// segment instead of once per 4-plane brick: (ZS+2)/ZS x (18 x 66)/(16 x 64) = 1.35 x the tensor at ZS = 12, where the
+// brick kernel above fetches 6 x 10 x 66 per 4 x 8 x 64 outputs = 1.93 x (PMC: 1.95 x, at the HBM ceiling).
+namespace c1z {
+constexpr int TY = 16, TX = 64, XT = 4, ZS = 12;
+constexpr int IY = TY + 2, IX = TX + 2, RW = 68;            // RW/4 odd: rows alternate 16-byte slot parity
+constexpr int PLANE = IY * RW;
+constexpr int PRAW = IY * IX;
+constexpr int NS = (PRAW + 255) / 256;
+constexpr int WMAXC = 128;                                   // channels whose taps fit the LDS image (14 KB)
+constexpr int CPS = 1;                                       // channels per step (per block barrier); 2 spills at four blocks per CU and is slower
+}  // namespace c1z
+
+__global__ __launch_bounds__(256, 4) void conv3d_c1z_kernel(ConvArgs a) {
+  using namespace c1z;
+  __shared__ __attribute__((aligned(16))) float in_s[2 * CPS * PLANE];
+  // the 27 taps of every channel, padded to 28 floats: read as seven broadcast ds_read_b128 a step ahead of their use.
+  // (Scalar loads would be the natural form -- the weights are wave-uniform -- but the output stores inside the loop
+  // keep the compiler from proving them unclobbered, and it falls back to vector-memory loads with a wait per step.)
+  __shared__ __attribute__((aligned(16))) float w_s[(WMAXC + CPS) * 28];
+  const int tid = threadIdx.x;
+  unsigned t = dv_xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = t % a.ntx; t /= a.ntx;
+  const int ty = t % a.nty; t /= a.nty;
+  const int tz = t % a.ntz;
+  const int b = t / a.ntz;
+  const int x0 = tx * TX, y0 = ty * TY, z0 = tz * ZS;
+  const int yl = tid >> 4, xs = (tid & 15) * XT;
+  const size_t plane = (size_t)a.H * a.W, vol = (size_t)a.D * plane;
+  const int ngrp = (a.Cin + CPS - 1) / CPS;                  // channel groups of CPS (the tail group's surplus is zeros)
+  for (int i = tid; i < ngrp * CPS * 28; i += 256) {
+    const int ch = i / 28, tap = i - ch * 28;
+    w_s[i] = (tap < 27 && ch < a.Cin) ? a.wpk[ch * 27 + tap] : 0.f;   // raw [1][Cin][27] weights
+  }
+
+  // staging plan of one haloed 18 x 66 plane: the same for every (plane, channel) step
+  unsigned sob[NS];
+  int slot[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int r = tid + 256 * i;
+    const int yy = r / IX, xx = r - yy * IX;
+    const int y = y0 - 1 + yy, x = x0 - 1 + xx;
+    const bool ok = r < PRAW && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+    sob[i] = ok ? (unsigned)(y * a.W + x) * 4u : 0x80000000u;
+    slot[i] = r < PRAW ? yy * RW + xx : IX;                 // column 66 of row 0: never read
+  }
+  const int plane_bytes = __builtin_amdgcn_readfirstlane((int)(plane * sizeof(float)));
+  const int vol_bytes = __builtin_amdgcn_readfirstlane((int)(vol * sizeof(float)));
+  const uint64_t in_b = reinterpret_cast<uint64_t>(a.in + (size_t)b * a.Cin * vol);
+  const uint64_t in_bs = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)in_b) |
+                         ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(in_b >> 32)) << 32);
+  // step s = (plane index s / ngrp, channel group s % ngrp); plane z = z0 - 1 + plane index.  The descriptor of a
+  // (plane, channel) starts at that plane of that channel and is one plane long: planes outside the volume and channels
+  // past the end get zero records (the z padding / the group tail)
+  const int nz = (a.D - z0 < ZS ? a.D - z0 : ZS) + 2;       // input planes this segment needs
+  const int nsteps = nz * ngrp;
+  float vin[CPS][NS];
+  int fz = z0 - 1, fg = 0;                                   // (plane, channel group) of the next fetch
+  auto fetch = [&]() __attribute__((always_inline)) {
+    const bool zok = (unsigned)fz < (unsigned)a.D;
+#pragma unroll
+    for (int k = 0; k < CPS; ++k) {
+      const int ch = fg * CPS + k;
+      const bool ok = zok && ch < a.Cin;
+      const uint64_t base = in_bs + (uint64_t)(unsigned)(ok ? ch : 0) * (uint64_t)(unsigned)vol_bytes +
+                            (uint64_t)(unsigned)(ok ? fz : 0) * (uint64_t)(unsigned)plane_bytes;
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(base), 0, ok ? plane_bytes : 0, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < NS; ++i)
+        vin[k][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)sob[i], 0, 0));
+    }
+    if (++fg == ngrp) { fg = 0; ++fz; }
+  };
+  auto commit = [&](float* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < CPS; ++k)
+#pragma unroll
+      for (int i = 0; i < NS; ++i) buf[k * PLANE + slot[i]] = vin[k][i];
+  };
+
+  const float sc = a.ch_scale ? a.ch_scale[0] : 1.f, bi = a.ch_bias ? a.ch_bias[0] : 0.f;
+  const int yo = y0 + yl, xo = x0 + xs;
+  const bool lane_in = yo < a.Ho && xo < a.Wo;
+  const size_t obase = (size_t)b * a.Do * a.Ho * a.Wo + (size_t)yo * a.Wo + xo;
+  auto emit = [&](const float (&acc)[XT], int zo) __attribute__((always_inline)) {   // output plane zo is complete
+    if (zo < z0 || zo >= z0 + ZS || zo >= a.Do || !lane_in) return;
+    const size_t o = obase + (size_t)zo * a.Ho * a.Wo;
+    float u[XT];
+#pragma unroll
+    for (int i = 0; i < XT; ++i) {
+      u[i] = fmaf(acc[i], sc, bi);
+      if (a.residual && xo + i < a.Wo) u[i] += a.residual[o + i];
+      u[i] = dv_act(u[i], a.act);
+    }
+    if (a.vec_store && xo + XT <= a.Wo) {
+      *reinterpret_cast<float4*>(a.out + o) = make_float4(u[0], u[1], u[2], u[3]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < XT; ++i)
+        if (xo + i < a.Wo) a.out[o + i] = u[i];
+    }
+  };
+
+  float accP[XT], accC[XT], accN[XT];                        // outputs at z - 1, z, z + 1 of the plane in flight
+#pragma unroll
+  for (int i = 0; i < XT; ++i) accP[i] = accC[i] = accN[i] = 0.f;
+
+  fetch();
+  commit(in_s);
+  fetch();
+  __syncthreads();
+  int g = 0, z = z0 - 1;
+  float4 wq[CPS][7];                                         // this step's taps
+#pragma unroll
+  for (int k = 0; k < CPS; ++k)
+#pragma unroll
+    for (int q = 0; q < 7; ++q) wq[k][q] = reinterpret_cast<const float4*>(w_s + k * 28)[q];
+#pragma unroll 1
+  for (int s = 0; s < nsteps; ++s) {
+    const float* cur = in_s + (s & 1) * (CPS * PLANE);
+    float* nxt = in_s + ((s + 1) & 1) * (CPS * PLANE);
+    float wc[CPS][28];
+#pragma unroll
+    for (int k = 0; k < CPS; ++k)
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        wc[k][4 * q] = wq[k][q].x; wc[k][4 * q + 1] = wq[k][q].y; wc[k][4 * q + 2] = wq[k][q].z; wc[k][4 * q + 3] = wq[k][q].w;
+      }
+    {
+      const int gn = g + 1 == ngrp ? 0 : g + 1;               // the next step's taps: in flight during this step
+#pragma unroll
+      for (int k = 0; k < CPS; ++k)
+#pragma unroll
+        for (int q = 0; q < 7; ++q) wq[k][q] = reinterpret_cast<const float4*>(w_s + (gn * CPS + k) * 28)[q];
+    }
+#pragma unroll
+    for (int k = 0; k < CPS; ++k) {
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        if (k == 0 && dy == 1) {                             // the next step's loads (issued one step ago) have landed
+          commit(nxt);
+          fetch();
+        }
+        const float* rp = cur + k * PLANE + (yl + dy) * RW + xs;
+        const float4 q0 = *reinterpret_cast<const float4*>(rp);
+        const float2 q1 = *reinterpret_cast<const float2*>(rp + 4);
+        const float v[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
+        // input plane z is tap dz of output plane z + 1 - dz: dz = 0 -> accN, 1 -> accC, 2 -> accP
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const float wN = wc[k][dy * 3 + dx], wC = wc[k][9 + dy * 3 + dx], wP = wc[k][18 + dy * 3 + dx];
+#pragma unroll
+          for (int i = 0; i < XT; ++i) {
+            accN[i] = fmaf(v[i + dx], wN, accN[i]);
+            accC[i] = fmaf(v[i + dx], wC, accC[i]);
+            accP[i] = fmaf(v[i + dx], wP, accP[i]);
+          }
+        }
+      }
+    }
+    if (++g == ngrp) {                                       // plane z is through: output z - 1 is complete
+      emit(accP, z - 1);
+#pragma unroll
+      for (int i = 0; i < XT; ++i) { accP[i] = accC[i]; accC[i] = accN[i]; accN[i] = 0.f; }
+      g = 0;
+      ++z;
+    }
+    __syncthreads();                                         // `cur` is free for step s + 2, `nxt` is complete
+  }
+}
+
+int launch_c1z(ConvArgs a, hipStream_t s) {
+  a.ntx = (a.Wo + c1z::TX - 1) / c1z::TX;
+  a.nty = (a.Ho + c1z::TY - 1) / c1z::TY;
+  a.ntz = (a.Do + c1z::ZS - 1) / c1z::ZS;
+  const long long blocks = (long long)a.B * a.ntz * a.nty * a.ntx;
+  if (blocks <= 0 || blocks > 0x7fffffffLL) return DV_ERR_SHAPE;
+  hipLaunchKernelGGL(conv3d_c1z_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  return dv_launch_status();
+}
+
 int launch_c1(ConvArgs a, hipStream_t s) {
+#ifndef DV_C1_BRICK
+  // plain inputs march along z (one fetch per voxel and segment) when the launch still fills the chip; the filter
+  // prologue and small launches keep the brick kernel.  DV_C1Z_MIN_BLOCKS (tests) moves the threshold.
+  static const long long min_blocks = getenv("DV_C1Z_MIN_BLOCKS") ? atoll(getenv("DV_C1Z_MIN_BLOCKS")) : 512;
+  if (!a.in_scale && a.Cin <= c1z::WMAXC && (long long)a.B * ((a.Do + c1z::ZS - 1) / c1z::ZS) * ((a.Ho + c1z::TY - 1) / c1z::TY) *
+                             ((a.Wo + c1z::TX - 1) / c1z::TX) >= min_blocks)
+    return launch_c1z(a, s);
+#endif
   a.ntx = (a.Wo + c1::TX - 1) / c1::TX;
   a.nty = (a.Ho + c1::TY - 1) / c1::TY;
   a.ntz = (a.Do + c1::TZ - 1) / c1::TZ;

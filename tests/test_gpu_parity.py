@@ -979,3 +979,37 @@ def test_precision_switch_selects_kernels(monkeypatch):
         S.set_default_conv_precision(None)
     monkeypatch.setenv("DV_CONV_PRECISION", "f32_direct")
     assert not S.Conv3dPlan(w3).wino
+
+
+def test_conv_single_channel_head_z_march():
+    """The z-marching form of the Cout == 1 head (csrc/conv3d.hip, conv3d_c1z_kernel: a 16 x 64 tile, segments of 12
+    output planes, three rotating accumulator sets) normally takes over only for launches of >= 512 blocks; here
+    DV_C1Z_MIN_BLOCKS=1 forces it (the threshold is read once per process, hence the child process) onto ragged shapes:
+    depth that is not a multiple of the segment, several segments, partial tiles in y and x, unaligned rows, channel
+    counts 1 .. 33, residual + ReLU.  Its results must also equal the brick kernel's to the layer bar."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from diffuvolume_amd import submodule as S
+from diffuvolume_amd.synth import _gen
+for cin, dims, extras in [(5, (1, 3, 5, 7), False), (33, (2, 13, 9, 70), True), (32, (1, 25, 18, 130), False),
+                          (1, (1, 1, 1, 1), False), (32, (1, 12, 16, 64), True), (7, (1, 27, 33, 67), True)]:
+    g = _gen(29, str((cin, dims)))
+    x = torch.randn(dims[0], cin, *dims[1:], generator=g)
+    w = torch.randn(1, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5
+    res = torch.randn(dims[0], 1, *dims[1:], generator=g) if extras else None
+    y = torch.nn.functional.conv3d(x.double(), w.double(), None, 1, 1)
+    if res is not None:
+        y = torch.relu(y + res.double())
+    plan = S.Conv3dPlan(w.cuda(), None, stride=1, act=S.ACT_RELU if extras else S.ACT_NONE)
+    out = plan(x.cuda(), residual=None if res is None else res.cuda())
+    err = float((out.cpu().double() - y).abs().max())
+    assert out.shape == y.shape and err <= 1e-5 * max(1.0, float(y.abs().max())), (cin, dims, err)
+print("OK")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DV_C1Z_MIN_BLOCKS="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

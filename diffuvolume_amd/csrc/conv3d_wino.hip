@@ -409,8 +409,9 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
     }
     // The uniform decisions (fast path, activation kind, residual) are taken ONCE per (plane, n): taken per element they
     // were a branch and four v_cndmask per stored row.
-    auto rows = [&](auto relu_c, auto res_c) __attribute__((always_inline)) {
-      constexpr bool RELU = decltype(relu_c)::value, RES = decltype(res_c)::value;
+    auto rows = [&](auto act_c, auto res_c) __attribute__((always_inline)) {
+      constexpr int ACTK = decltype(act_c)::value;          // 0 = identity, 1 = ReLU, 2 = whatever a.act says
+      constexpr bool RELU = ACTK == 1, RES = decltype(res_c)::value;
 #pragma unroll
       for (int tr = 0; tr < 2; ++tr) {     // tile row
 #pragma unroll
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
             // max(v, v*0): NaN stays NaN as in torch.relu; two instructions per element and no VCC round trip (a compare
             // + select costs two wait states per element on gfx950)
             v = __builtin_elementwise_max(v, v * 0.f);
-          } else {
+          } else if (ACTK == 2) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = mish ? dv_act(v[e], DV_ACT_MISH) : fmaxf(v[e], v[e] * slope);
           }
@@ -432,11 +433,19 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
       }
     };
     if (fast) {
-      const bool relu = a.act == DV_ACT_RELU;
-      if (relu && a.residual) rows(std::true_type{}, std::true_type{});
-      else if (relu) rows(std::true_type{}, std::false_type{});
-      else if (a.residual) rows(std::false_type{}, std::true_type{});
-      else rows(std::false_type{}, std::false_type{});
+      using K0 = std::integral_constant<int, 0>;
+      using K1 = std::integral_constant<int, 1>;
+      using K2 = std::integral_constant<int, 2>;
+      if (a.act == DV_ACT_RELU) {
+        if (a.residual) rows(K1{}, std::true_type{});
+        else rows(K1{}, std::false_type{});
+      } else if (a.act == DV_ACT_NONE) {          // (the residual layer of dres1, acv_ddim.py:262)
+        if (a.residual) rows(K0{}, std::true_type{});
+        else rows(K0{}, std::false_type{});
+      } else {
+        if (a.residual) rows(K2{}, std::true_type{});
+        else rows(K2{}, std::false_type{});
+      }
     } else {
 #pragma unroll
       for (int tr = 0; tr < 2; ++tr) {

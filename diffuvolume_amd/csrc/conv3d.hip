@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256, 4) void conv3d_c1_kernel(ConvArgs a) {
 // segment instead of once per 4-plane brick: (ZS+2)/ZS x (18 x 66)/(16 x 64) = 1.35 x the tensor at ZS = 12, where the
 // brick kernel above fetches 6 x 10 x 66 per 4 x 8 x 64 outputs = 1.93 x (PMC: 1.95 x, at the HBM ceiling).
 namespace c1z {
-constexpr int TY = 16, TX = 64, XT = 4, ZS = 12;
+constexpr int TY = 16, TX = 64, XT = 4;                     // (ZS, the planes of a segment, is a template parameter)
 constexpr int IY = TY + 2, IX = TX + 2, RW = 68;            // RW/4 odd: rows alternate 16-byte slot parity
 constexpr int PLANE = IY * RW;
 constexpr int PRAW = IY * IX;
@@ -480,6 +480,7 @@ constexpr int WMAXC = 128;                                   // channels whose t
 constexpr int CPS = 1;                                       // channels per step (per block barrier); 2 spills at four blocks per CU and is slower
 }  // namespace c1z
 
+template <int ZS>
 __global__ __launch_bounds__(256, 4) void conv3d_c1z_kernel(ConvArgs a) {
   using namespace c1z;
   __shared__ __attribute__((aligned(16))) float in_s[2 * CPS * PLANE];
@@ -639,24 +640,35 @@ __global__ __launch_bounds__(256, 4) void conv3d_c1z_kernel(ConvArgs a) {
   }
 }
 
+template <int ZS>
 int launch_c1z(ConvArgs a, hipStream_t s) {
   a.ntx = (a.Wo + c1z::TX - 1) / c1z::TX;
   a.nty = (a.Ho + c1z::TY - 1) / c1z::TY;
-  a.ntz = (a.Do + c1z::ZS - 1) / c1z::ZS;
+  a.ntz = (a.Do + ZS - 1) / ZS;
   const long long blocks = (long long)a.B * a.ntz * a.nty * a.ntx;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return DV_ERR_SHAPE;
-  hipLaunchKernelGGL(conv3d_c1z_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(conv3d_c1z_kernel<ZS>, dim3((unsigned)blocks), dim3(256), 0, s, a);
   return dv_launch_status();
 }
 
 int launch_c1(ConvArgs a, hipStream_t s) {
 #ifndef DV_C1_BRICK
-  // plain inputs march along z (one fetch per voxel and segment) when the launch still fills the chip; the filter
-  // prologue and small launches keep the brick kernel.  DV_C1Z_MIN_BLOCKS (tests) moves the threshold.
-  static const long long min_blocks = getenv("DV_C1Z_MIN_BLOCKS") ? atoll(getenv("DV_C1Z_MIN_BLOCKS")) : 512;
-  if (!a.in_scale && a.Cin <= c1z::WMAXC && (long long)a.B * ((a.Do + c1z::ZS - 1) / c1z::ZS) * ((a.Ho + c1z::TY - 1) / c1z::TY) *
-                             ((a.Wo + c1z::TX - 1) / c1z::TX) >= min_blocks)
-    return launch_c1z(a, s);
+  // Plain inputs march along z (one fetch per voxel and segment); the filter prologue and small volumes keep the brick
+  // kernel.  WHICH kernel runs must not depend on the batch size -- the two add in different orders, and a shard of a
+  // batch has to produce the bits the whole batch produces (tests/test_gpu_fullsize.py, the multi-GPU sharding) -- so the
+  // choice looks at one batch item only.  The segment length may follow the batch: every output is summed plane by
+  // plane, channel by channel whatever segment it lies in, so ZS changes the block count and not a single bit.
+  // DV_C1Z_MIN_BLOCKS / DV_C1Z_ZS (tests) move the threshold / pin the segment length.
+  static const long long min_pp = getenv("DV_C1Z_MIN_BLOCKS") ? atoll(getenv("DV_C1Z_MIN_BLOCKS")) : 64;
+  static const int pin_zs = getenv("DV_C1Z_ZS") ? atoi(getenv("DV_C1Z_ZS")) : 0;
+  const long long tiles = (long long)((a.Ho + c1z::TY - 1) / c1z::TY) * ((a.Wo + c1z::TX - 1) / c1z::TX);
+  auto blocks_at = [&](int zs) { return (long long)a.B * ((a.Do + zs - 1) / zs) * tiles; };
+  if (!a.in_scale && a.Cin <= c1z::WMAXC && ((a.Do + 2) / 3) * tiles >= min_pp) {
+    const int zs = pin_zs ? pin_zs : (blocks_at(12) >= 512 ? 12 : (blocks_at(6) >= 512 ? 6 : 3));
+    if (zs >= 12) return launch_c1z<12>(a, s);
+    if (zs >= 6) return launch_c1z<6>(a, s);
+    return launch_c1z<3>(a, s);
+  }
 #endif
   a.ntx = (a.Wo + c1::TX - 1) / c1::TX;
   a.nty = (a.Ho + c1::TY - 1) / c1::TY;

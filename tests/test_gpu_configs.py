@@ -89,7 +89,10 @@ def test_fused_volume_and_loop_vs_oracle(setup):
     # statement the 2 % above cannot make: two fp32 evaluations of this untrained refinement stack differ by their sum
     sd64 = {k: (v.double() if v.is_floating_point() and not k.startswith("time_embedding") else v) for k, v in sd.items()}
     f64 = lambda feats: {k: v.double() for k, v in feats.items()}
-    tri = LP.teacher_forced_vs_fp64(m, orc, P.PCWDiffusionOracle(sd64), trace, vol, vol_d, batch["used"][:1],
+    # (default: the first step only -- the float64 oracle of this flavour costs ~40 s of CPU per step; DV_FULL_PARITY=1: all
+    # three, which is how profiles/r03_parity_config4_fp64_triangulation.json was made)
+    full = __import__("os").environ.get("DV_FULL_PARITY") == "1"
+    tri = LP.teacher_forced_vs_fp64(m, orc, P.PCWDiffusionOracle(sd64), trace if full else trace[:1], vol, vol_d, batch["used"][:1],
                                     oracle_args=(f64(fl0), f64(fr0)), features_left=dl, features_right=dr)
     import json
     import os

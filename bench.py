@@ -199,6 +199,20 @@ def dry_run(a):
     return 0
 
 
+def under_launcher() -> bool:
+    """A real launcher environment: RANK, LOCAL_RANK, WORLD_SIZE and MASTER_PORT all set (torchrun, or this script
+    launching its own ranks).  A bare WORLD_SIZE=1 exported by a scheduler does not start a process group."""
+    return all(k in os.environ for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"))
+
+
+def launcher_label() -> str:
+    if os.environ.get("DV_BENCH_SELF_LAUNCHED"):
+        return "self"
+    if os.environ.get("TORCHELASTIC_RUN_ID"):
+        return "torchrun"
+    return "env" if under_launcher() else "single"
+
+
 def make_inputs(batch, h, w, seed, device):
     """Synthetic quarter-resolution features with a real correlation ridge."""
     from diffuvolume_amd.synth import synth_hot_inputs
@@ -210,7 +224,9 @@ def hot_path(model, x, tape=None):
     """One pass of the hot path; returns (final disparity, per-step stack, gwc volume)."""
     import diffuvolume_amd as dv
     gwc = dv.build_gwc_volume(x["fl"], x["fr"], 48, 40)
-    vol = dv.build_concat_attention_volume(x["cl"], x["cr"], x["att"], 48)
+    # the attention-concat volume as its factors (what ACVNet_DDIM.forward passes): its one consumer, dres0[0], reads
+    # the factors, so the [B,64,48,h,w] tensor of acv_ddim.py:390 is not written (config: "attention_concat_volume")
+    vol = dv.build_concat_attention_volume(x["cl"], x["cr"], x["att"], 48, lazy=True)
     x_T = model.encode_disparity(x["dq"])
     final, stack = model.ddim_sample(vol, x["used"], x_T, noise=tape)
     return final, stack, gwc
@@ -412,7 +428,7 @@ def main():
     from diffuvolume_amd import distributed as D
     # under a launcher (WORLD_SIZE set, even to 1) the process group is always initialised: `torchrun --nproc-per-node 1`
     # goes through RCCL exactly like N = 8
-    rank, world, local = D.init_from_env(force="WORLD_SIZE" in os.environ)
+    rank, world, local = D.init_from_env(force=under_launcher())
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: refusing to report a different GPU count")
     assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU visible"
@@ -487,10 +503,12 @@ def main():
         "config": {"workload": f"SceneFlow ACVNet+DiffuVolume hot path (gwc + concat*softmax(att) + "
                                f"{a.ddim_steps} DDIM steps + EPE), {a.width}x{a.height}, maxdisp=192, "
                                f"batch={a.batch}/GPU, random-init weights",
-                   "global_batch": a.batch * world, "ddim_steps": a.ddim_steps, "parallelism": f"dp{world}"},
+                   "global_batch": a.batch * world, "ddim_steps": a.ddim_steps, "parallelism": f"dp{world}",
+                   "attention_concat_volume": "factors only (softmax(att) + the two feature maps; its one consumer, "
+                                              "dres0[0], runs on them): the [B,64,48,h,w] tensor is not materialised"},
         "rccl_ranks": rccl_ranks,
         "dist_backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
-        "launcher": "self" if os.environ.get("DV_BENCH_SELF_LAUNCHED") else ("torchrun" if "WORLD_SIZE" in os.environ else "single"),
+        "launcher": launcher_label(),
         "epe_px": epe["EPE"],
         "epe_note": "random-init weights and synthetic pairs: the number only shows the metric path runs; dataset EPE "
                     "(0.46 px, README) is unpinned -- no checkpoint or data ship with the reference",

@@ -36,6 +36,7 @@ SIGNATURES = {
     "dv_gwc_volume_f32": (c_int, [P, P, P, I, I, I, I, I, I, P]),
     "dv_concat_volume_f32": (c_int, [P, P, P, I, I, I, I, I, I, P]),
     "dv_concat_attn_volume_f32": (c_int, [P, P, P, P, I, I, I, I, I, P]),
+    "dv_concat_prob_volume_f32": (c_int, [P, P, P, P, I, I, I, I, I, P]),
     "dv_softmax_d_f32": (c_int, [P, P, I, I, I, P]),
     "dv_mul_f32": (c_int, [P, P, P, c_size_t, P]),
     "dv_conv3d_rank1_filter_f32": (c_int, [P, P, P, P, P, P, I, I, I, I, I, I, P]),

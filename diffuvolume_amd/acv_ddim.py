@@ -29,7 +29,7 @@ from . import _lib
 from .head import DynamicHead
 from .submodule import (ACT_NONE, ACT_RELU, Conv2dPlan, Conv3dPlan, Deconv3dPlan, Rank1FilterPlan, ReplicaPlanCache,
                         _dev_f32,
-                        build_concat_attention_volume, build_gwc_volume, check_split_overflow,
+                        AttentionConcatVolume, build_concat_attention_volume, build_gwc_volume, check_split_overflow,
                         default_conv_precision, patch_volume, upsample_softmax_regress, window_attention)
 
 
@@ -287,6 +287,15 @@ class _Plans:
         self.weights_version = -1
 
 
+def _volume_arg(volume):
+    """The `volume` argument of the reference API: a float32 device tensor, or the factor handle standing in for it."""
+    return volume if isinstance(volume, AttentionConcatVolume) else _dev_f32(volume, "volume")
+
+
+def _volume_tensor(volume) -> torch.Tensor:
+    return volume.tensor() if isinstance(volume, AttentionConcatVolume) else volume
+
+
 class _LoopStep:
     """Everything one DDIM step needs that depends only on its timestep: the coefficient struct handed to
     ``dv_ddim_step`` by value and the time-MLP shift (device resident; one row per batch entry on demand)."""
@@ -498,8 +507,8 @@ class ACVNet_DDIM(_HipPlanMixin):
         r1 = getattr(p, "dres0_rank1", None)
         if r1 is not None and r1.applies(volume):
             cost0 = p.dres0.second(r1(volume, n01f))            # first layer on the volume's factors (Rank1FilterPlan)
-        else:
-            cost0 = p.dres0(volume, in_scale=n01f)
+        else:                                                   # any other tensor; a factor handle is materialised once
+            cost0 = p.dres0(_volume_tensor(volume), in_scale=n01f)
         cost0 = p.dres1(cost0, residual_self=True)
         out2 = p.dres3(p.dres2(cost0))
         return p.classif2(out2)
@@ -571,7 +580,7 @@ class ACVNet_DDIM(_HipPlanMixin):
     @torch.no_grad()
     def model_predictions(self, volume: torch.Tensor, noise: torch.Tensor, t: torch.Tensor):
         """acv_ddim.py:254-296 -> (pred_noise fp64, x_start fp32, pred [B,H,W], ProbVolumeHandle)."""
-        volume = _dev_f32(volume, "volume")
+        volume = _volume_arg(volume)
         b, _, d, h, w = volume.shape
         self.prepare(check_weights=True)
         with torch.cuda.device(volume.device):
@@ -610,7 +619,7 @@ class ACVNet_DDIM(_HipPlanMixin):
         'fill' = rand_like :360) injects the random draws for parity tests; by default they come
         from the device generator.  ``trace(i, state)`` (tests) receives every step's tensors.
         Returns (final_prediction [B,H,W], stack [S+1,B,H,W])."""
-        volume = _dev_f32(volume, "volume")
+        volume = _volume_arg(volume)
         used = self._check_loop_args(volume, _dev_f32(used, "used"), asd)
         b, _, d, h, w = volume.shape
         dev = volume.device
@@ -662,16 +671,18 @@ class ACVNet_DDIM(_HipPlanMixin):
         return x
 
     @torch.no_grad()
-    def attention_concat_volume(self, feat_left: torch.Tensor, feat_right: torch.Tensor) -> torch.Tensor:
+    def attention_concat_volume(self, feat_left: torch.Tensor, feat_right: torch.Tensor, lazy: bool = True):
         """acv_ddim.py:375-390: gwc volume -> patch convs -> attention aggregation -> logits, then the
-        softmax-weighted concat volume (the tensor the DDIM loop filters)."""
+        softmax-weighted concat volume (the tensor the DDIM loop filters) -- by default as its factors
+        (``AttentionConcatVolume``: the first aggregation layer reads nothing else, so the 3 GB tensor of :390 is
+        not written); ``lazy=False`` returns the tensor."""
         p = self.prepare()
         gwc = build_gwc_volume(feat_left, feat_right, self.maxdisp // 4, self.num_groups)
         att = p.dres1_att(patch_volume(gwc, p.patch_w1, p.patch_w2, p.patch_dil))     # patch, patch_l1..3 (:377-381)
         att = p.classif_att(p.dres2_att(att))
         cl = p.concat_b(p.concat_a(feat_left))
         cr = p.concat_b(p.concat_a(feat_right))
-        return build_concat_attention_volume(cl, cr, att, self.maxdisp // 4)
+        return build_concat_attention_volume(cl, cr, att, self.maxdisp // 4, lazy=lazy)
 
     def forward(self, left, right, used, disp, mask_gt=None):
         if self.training:

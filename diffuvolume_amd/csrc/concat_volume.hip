@@ -12,13 +12,17 @@
 // the same time (round 1 had one row per block, waves on different disparities: 960-byte bursts scattered 122 KB
 // apart, 3.6 TB/s) and every wave computes the softmax normaliser of its own row only.  The shifted target comes
 // from LDS (rows staged once behind a zero pad) with two ds_read_b128 per 4x4 register tile.
+// ATT: 0 = plain concatenation, 1 = attention LOGITS (softmax computed here), 2 = attention PROBABILITIES (the softmax
+// was taken by dv_softmax_d_f32 -- same arithmetic, same bits -- and is only multiplied in).  The channel chunks of
+// one 4-row slab are neighbours in the XCD-aware block order (dv_xcd_remap), so the attention rows they all read come
+// from HBM once and from that XCD's L2 afterwards; the left feature values of a chunk are loaded once per thread.
 #include "dv_common.h"
 
 namespace {
 
 constexpr int kChunk = 8;  // channels of each half per block
 
-template <bool ATT, bool ZERO_LEFT>
+template <int ATT, bool ZERO_LEFT>
 __global__ __launch_bounds__(256) void concat_rows_kernel(const float* __restrict__ ref,
                                                           const float* __restrict__ tgt,
                                                           const float* __restrict__ att,
@@ -35,8 +39,9 @@ __global__ __launch_bounds__(256) void concat_rows_kernel(const float* __restric
 
   const int nchunks = (C + kChunk - 1) / kChunk;
   const int nyt = (H + 3) >> 2;
-  const int cchunk = blockIdx.x % nchunks;
-  const int by = blockIdx.x / nchunks;
+  const unsigned bid = dv_xcd_remap(blockIdx.x, gridDim.x);
+  const int cchunk = bid % nchunks;
+  const int by = bid / nchunks;
   const int y0 = (by % nyt) * 4;
   const int b = by / nyt;
   const int c0 = cchunk * kChunk;
@@ -63,7 +68,7 @@ __global__ __launch_bounds__(256) void concat_rows_kernel(const float* __restric
 
   for (int t = lane; t < nq; t += DV_WAVE) {
     float4 mx = make_float4(0.f, 0.f, 0.f, 0.f), rs = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (ATT) {
+    if (ATT == 1) {
       mx = reinterpret_cast<const float4*>(attrow)[t];
       for (int d = 1; d < D; ++d) {
         const float4 a = reinterpret_cast<const float4*>(attrow + (size_t)d * plane)[t];
@@ -79,22 +84,32 @@ __global__ __launch_bounds__(256) void concat_rows_kernel(const float* __restric
       }
       rs = make_float4(1.f / sum.x, 1.f / sum.y, 1.f / sum.z, 1.f / sum.w);
     }
+    float l[kChunk][4];
+#pragma unroll
+    for (int c = 0; c < kChunk; ++c) {
+      const float4 Lq = c < nc ? reinterpret_cast<const float4*>(ref + ((size_t)b * C + c0 + c) * plane + (size_t)y * W)[t]
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+      l[c][0] = Lq.x; l[c][1] = Lq.y; l[c][2] = Lq.z; l[c][3] = Lq.w;
+    }
     for (int e = 0; e < eblocks; ++e) {
       float p[4][4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int d = 4 * e + r;
-        if (ATT && d < D) {
+        if (ATT == 1 && d < D) {
           const float4 a = reinterpret_cast<const float4*>(attrow + (size_t)d * plane)[t];
           p[r][0] = dv_exp_le0(a.x - mx.x) * rs.x; p[r][1] = dv_exp_le0(a.y - mx.y) * rs.y;
           p[r][2] = dv_exp_le0(a.z - mx.z) * rs.z; p[r][3] = dv_exp_le0(a.w - mx.w) * rs.w;
+        } else if (ATT == 2 && d < D) {
+          const float4 a = reinterpret_cast<const float4*>(attrow + (size_t)d * plane)[t];
+          p[r][0] = a.x; p[r][1] = a.y; p[r][2] = a.z; p[r][3] = a.w;
         } else {
           p[r][0] = p[r][1] = p[r][2] = p[r][3] = 1.f;
         }
       }
-      for (int c = 0; c < nc; ++c) {
-        const float4 Lq = reinterpret_cast<const float4*>(ref + ((size_t)b * C + c0 + c) * plane + (size_t)y * W)[t];
-        const float l[4] = {Lq.x, Lq.y, Lq.z, Lq.w};
+#pragma unroll
+      for (int c = 0; c < kChunk; ++c) {
+        if (c >= nc) break;
         const float4 lo = rows[c * rowq + padq + t - e - 1];
         const float4 hi = rows[c * rowq + padq + t - e];
         const float w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -105,7 +120,7 @@ __global__ __launch_bounds__(256) void concat_rows_kernel(const float* __restric
             float vl[4], vr[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              float lv = l[j];
+              float lv = l[c][j];
               if (ZERO_LEFT && (4 * t + j) < d) lv = 0.f;
               vl[j] = ATT ? p[r][j] * lv : lv;
               vr[j] = ATT ? p[r][j] * w[4 + j - r] : w[4 + j - r];
@@ -122,7 +137,7 @@ __global__ __launch_bounds__(256) void concat_rows_kernel(const float* __restric
 }
 
 // Any W / alignment: one thread per output element.
-template <bool ATT, bool ZERO_LEFT>
+template <int ATT, bool ZERO_LEFT>
 __global__ void concat_generic_kernel(const float* __restrict__ ref, const float* __restrict__ tgt,
                                       const float* __restrict__ att, float* __restrict__ out, int C,
                                       int H, int W, int D, size_t total) {
@@ -142,20 +157,22 @@ __global__ void concat_generic_kernel(const float* __restrict__ ref, const float
     } else {
       v = x >= d ? tgt[(((size_t)b * C + (c - C)) * H + y) * W + x - d] : 0.f;
     }
-    if (ATT) {
+    if (ATT == 2) {
+      v *= att[(((size_t)b * D + d) * H + y) * W + x];
+    } else if (ATT == 1) {
       const float* a = att + ((size_t)b * D * H + y) * W + x;
       const size_t plane = (size_t)H * W;
       float mx = a[0];
       for (int k = 1; k < D; ++k) mx = fmaxf(mx, a[k * plane]);
       float sum = 0.f;
-      for (int k = 0; k < D; ++k) sum += expf(a[k * plane] - mx);
-      v *= expf(a[d * plane] - mx) / sum;
+      for (int k = 0; k < D; ++k) sum += dv_exp_le0(a[k * plane] - mx);
+      v *= dv_exp_le0(a[d * plane] - mx) * (1.f / sum);
     }
     out[i] = v;
   }
 }
 
-template <bool ATT, bool ZL>
+template <int ATT, bool ZL>
 int launch(const float* ref, const float* tgt, const float* att, float* out, int B, int C, int H,
            int W, int D, hipStream_t s) {
   const bool fast = (W % 4 == 0) && dv_aligned16(ref) && dv_aligned16(tgt) && dv_aligned16(out) &&
@@ -184,8 +201,8 @@ extern "C" int dv_concat_volume_f32(const float* ref, const float* tgt, float* o
   DV_REQUIRE_PTR(out);
   DV_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && D > 0, DV_ERR_SHAPE);
   hipStream_t s = (hipStream_t)stream;
-  return zero_left ? launch<false, true>(ref, tgt, nullptr, out, B, C, H, W, D, s)
-                   : launch<false, false>(ref, tgt, nullptr, out, B, C, H, W, D, s);
+  return zero_left ? launch<0, true>(ref, tgt, nullptr, out, B, C, H, W, D, s)
+                   : launch<0, false>(ref, tgt, nullptr, out, B, C, H, W, D, s);
 }
 
 extern "C" int dv_concat_attn_volume_f32(const float* ref, const float* tgt, const float* att,
@@ -196,5 +213,15 @@ extern "C" int dv_concat_attn_volume_f32(const float* ref, const float* tgt, con
   DV_REQUIRE_PTR(att);
   DV_REQUIRE_PTR(out);
   DV_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && D > 0, DV_ERR_SHAPE);
-  return launch<true, false>(ref, tgt, att, out, B, C, H, W, D, (hipStream_t)stream);
+  return launch<1, false>(ref, tgt, att, out, B, C, H, W, D, (hipStream_t)stream);
+}
+
+extern "C" int dv_concat_prob_volume_f32(const float* ref, const float* tgt, const float* p, float* out, int B, int C,
+                                         int H, int W, int D, dv_stream_t stream) {
+  DV_REQUIRE_PTR(ref);
+  DV_REQUIRE_PTR(tgt);
+  DV_REQUIRE_PTR(p);
+  DV_REQUIRE_PTR(out);
+  DV_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && D > 0, DV_ERR_SHAPE);
+  return launch<2, false>(ref, tgt, p, out, B, C, H, W, D, (hipStream_t)stream);
 }

@@ -274,8 +274,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       for (int c = 0; c < 2; ++c) {
         float v = fmaf(acc[c], sc[c], bi[c]);
         v = decltype(mishc)::value ? dv_act(v, DV_ACT_MISH) : fmaxf(v, v * slope);
-        // (a missing second channel lies beyond the descriptor's nch volumes: that store is dropped)
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ors, ooff, c * vol_bytes + d * plane_b, 0);
+        // an odd Cout has no second channel in its last pair: skipped by a wave-uniform test (the descriptor's range
+        // check is not relied on here -- the scalar offset enters it as num_records - soffset, which would wrap)
+        if (c < nch)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ors, ooff, c * vol_bytes + d * plane_b, 0);
       }
     }
   };

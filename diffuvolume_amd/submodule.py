@@ -18,7 +18,8 @@ import torch
 from . import _lib
 from .profiling import WINO_MULT_REDUCTION, timed
 
-__all__ = ["build_gwc_volume", "build_concat_volume", "build_concat_attention_volume",
+__all__ = ["build_gwc_volume", "build_concat_volume", "build_concat_attention_volume", "AttentionConcatVolume",
+           "volume_factors",
            "disparity_regression", "upsample_softmax_regress", "Conv3dPlan", "Conv2dPlan", "Deconv3dPlan",
            "window_attention", "feature_gate", "softmax_regress", "refine_inputs", "patch_volume", "ACT_NONE", "ACT_RELU", "ACT_MISH", "ACT_LEAKY", "ACT_SIGMOID", "ACT_TANH"]
 
@@ -173,16 +174,78 @@ def build_concat_volume(refimg_fea: torch.Tensor, targetimg_fea: torch.Tensor, m
     return out
 
 
-def build_concat_attention_volume(refimg_fea: torch.Tensor, targetimg_fea: torch.Tensor,
-                                  att_weights: torch.Tensor, maxdisp: int) -> torch.Tensor:
-    """``F.softmax(att_weights, dim=2) * build_concat_volume(...)`` in one pass
-    (acv_ddim.py:388-390).  att_weights [B,1,maxdisp,H,W] are logits."""
+class AttentionConcatVolume:
+    """``F.softmax(att_weights, dim=2) * build_concat_volume(left, right)`` (acv_ddim.py:388-390) kept as its three
+    FACTORS -- p = softmax(att) [B,D,h,w] and the two feature maps [B,C,h,w] -- instead of the [B,2C,D,h,w] tensor
+    (3.0 GB at batch 8).  The first aggregation layer of every DDIM step reads the factors (``Rank1FilterPlan``), so on
+    the model's own path the tensor is never written; ``tensor()`` materialises it (once) for any other consumer.
+    The factors are private copies: nothing the caller does to its feature tensors afterwards can reach them."""
+
+    def __init__(self, p_att: torch.Tensor, ref: torch.Tensor, tgt: torch.Tensor):
+        self.p_att, self.ref, self.tgt = p_att, ref, tgt
+        b, d, h, w = p_att.shape
+        self.shape = torch.Size((b, 2 * ref.shape[1], d, h, w))
+        self.device, self.dtype = p_att.device, p_att.dtype
+        self._tensor: Optional[torch.Tensor] = None
+        self._rank1_tables = None
+
+    def dim(self) -> int:
+        return 5
+
+    def size(self, i: Optional[int] = None):
+        return self.shape if i is None else self.shape[i]
+
+    def numel(self) -> int:
+        return self.shape.numel()
+
+    def tensor(self) -> torch.Tensor:
+        """The materialised [B,2C,D,h,w] volume (``dv_concat_attn_volume_f32`` run on p directly)."""
+        if self._tensor is None:
+            b, c2, d, h, w = self.shape
+            out = torch.empty(tuple(self.shape), dtype=torch.float32, device=self.device)
+            lib = _lib.load()
+            with torch.cuda.device(self.device):
+                timed("concat_attn_volume", 2.0 * out.numel(),
+                      4.0 * (2 * self.ref.numel() + self.p_att.numel() + out.numel()),
+                      lambda: _lib.check(lib.dv_concat_prob_volume_f32(self.ref.data_ptr(), self.tgt.data_ptr(),
+                                                                       self.p_att.data_ptr(), out.data_ptr(), b, c2 // 2,
+                                                                       h, w, d, _lib.stream_ptr()),
+                                         "dv_concat_prob_volume_f32"))
+            self._tensor = out
+        return self._tensor
+
+
+def _attention_factors(refimg_fea, targetimg_fea, att_weights, maxdisp):
     ref = _dev_f32(refimg_fea, "refimg_fea")
     tgt = _dev_f32(targetimg_fea, "targetimg_fea")
     att = _dev_f32(att_weights, "att_weights")
     b, c, h, w = ref.shape
     if ref.shape != tgt.shape or tuple(att.shape) != (b, 1, maxdisp, h, w):
         raise RuntimeError("shape mismatch between features and attention weights")
+    p_att = torch.empty((b, maxdisp, h, w), dtype=torch.float32, device=ref.device)
+    with torch.cuda.device(ref.device):
+        _lib.check(_lib.load().dv_softmax_d_f32(att.data_ptr(), p_att.data_ptr(), b, maxdisp, h * w, _lib.stream_ptr()),
+                   "dv_softmax_d_f32")
+    return ref, tgt, att, p_att
+
+
+def build_concat_attention_volume(refimg_fea: torch.Tensor, targetimg_fea: torch.Tensor,
+                                  att_weights: torch.Tensor, maxdisp: int, lazy: bool = False):
+    """``F.softmax(att_weights, dim=2) * build_concat_volume(...)`` in one pass
+    (acv_ddim.py:388-390).  att_weights [B,1,maxdisp,H,W] are logits.
+
+    ``lazy=False`` (default): the [B,2C,maxdisp,H,W] tensor, with private copies of its factors riding along so that
+    ``ACVNet_DDIM`` can run its first aggregation layer on them; the ride-along is void the moment the tensor is
+    edited in place (``Rank1FilterPlan.applies`` compares ``_version``).  ``lazy=True``: an ``AttentionConcatVolume``
+    -- the factors only, nothing of the volume written -- which ``ACVNet_DDIM.ddim_sample / model_predictions`` accept
+    in the tensor's place (what ``ACVNet_DDIM.forward`` passes itself)."""
+    ref, tgt, att, p_att = _attention_factors(refimg_fea, targetimg_fea, att_weights, maxdisp)
+    b, c, h, w = ref.shape
+    # private copies (2 x 31 MB at batch 8): `ref` / `tgt` may BE the caller's tensors (`contiguous()` of a contiguous
+    # tensor is the tensor itself), and the rank-1 tables are built from them later, on the first DDIM step
+    handle = AttentionConcatVolume(p_att, ref.clone(), tgt.clone())
+    if lazy:
+        return handle
     out = torch.empty((b, 2 * c, maxdisp, h, w), dtype=torch.float32, device=ref.device)
     lib = _lib.load()
     with torch.cuda.device(ref.device):
@@ -190,13 +253,21 @@ def build_concat_attention_volume(refimg_fea: torch.Tensor, targetimg_fea: torch
               lambda: _lib.check(lib.dv_concat_attn_volume_f32(ref.data_ptr(), tgt.data_ptr(), att.data_ptr(),
                                                                out.data_ptr(), b, c, h, w, maxdisp,
                                                                _lib.stream_ptr()), "dv_concat_attn_volume_f32"))
-        # the factors of this volume (softmax(att) and the two feature maps) ride along: the first aggregation layer
-        # of every DDIM step can then run on them instead of on the 64-channel volume (Rank1FilterPlan)
-        p_att = torch.empty((b, maxdisp, h, w), dtype=torch.float32, device=ref.device)
-        _lib.check(lib.dv_softmax_d_f32(att.data_ptr(), p_att.data_ptr(), b, maxdisp, h * w, _lib.stream_ptr()),
-                   "dv_softmax_d_f32")
-    out._dv_factors = (p_att, ref, tgt)
+    out._dv_factors = handle
+    out._dv_factors_version = out._version
     return out
+
+
+def volume_factors(volume) -> Optional[AttentionConcatVolume]:
+    """The factors a volume may be replaced by: the handle itself, or the ride-along of a tensor that
+    ``build_concat_attention_volume`` returned and that has not been written to since (any in-place operation on the
+    tensor bumps ``_version``; a clone / slice / arithmetic result is a new tensor without the attribute)."""
+    if isinstance(volume, AttentionConcatVolume):
+        return volume
+    fac = getattr(volume, "_dv_factors", None)
+    if fac is None or getattr(volume, "_dv_factors_version", None) != volume._version:
+        return None
+    return fac
 
 
 def disparity_regression(x: torch.Tensor, maxdisp: int, keepdim: bool = False) -> torch.Tensor:
@@ -388,8 +459,10 @@ class ReplicaPlanCache:
         replica.__dict__["_plan_source"] = self.__dict__.get("_plan_source") or self
         return replica
 
-    def _source_version(self, src) -> int:
-        return sum(t._version for t in src.parameters()) + sum(t._version for t in src.buffers())
+    def _source_version(self, src):
+        """Identity of the source's weight set: (storage address, in-place version) of every parameter and buffer -- a
+        weight replaced through ``param.data = ...`` changes the address, an in-place write the version."""
+        return tuple((t.data_ptr(), t._version) for t in list(src.parameters()) + list(src.buffers()))
 
     def _replica_lookup(self, device):
         src = self._replica_source()
@@ -432,24 +505,25 @@ class Rank1FilterPlan:
         self.table_r = Conv2dPlan(wr, None, act=ACT_NONE)
         self.scale, self.shift = _fold_bn(bn, None, self.cout, w.device, eps)
 
-    def applies(self, volume: torch.Tensor) -> bool:
-        fac = getattr(volume, "_dv_factors", None)
-        return (fac is not None and volume.dim() == 5 and volume.shape[1] == 2 * self.c and volume.shape[2] <= self.MAX_D
-                and fac[1].shape[1] == self.c and tuple(fac[0].shape) == (volume.shape[0],) + tuple(volume.shape[2:]))
+    def applies(self, volume) -> bool:
+        fac = volume_factors(volume)
+        return (fac is not None and len(volume.shape) == 5 and volume.shape[1] == 2 * self.c
+                and volume.shape[2] <= self.MAX_D and fac.ref.shape[1] == self.c
+                and tuple(fac.p_att.shape) == (volume.shape[0],) + tuple(volume.shape[2:]))
 
-    def tables(self, volume: torch.Tensor):
-        """(GL, GR) [B, 27*Cout, h, w] of a volume's feature maps, cached on the volume object."""
-        cached = getattr(volume, "_dv_rank1_tables", None)
+    def tables(self, volume):
+        """(GL, GR) [B, 27*Cout, h, w] of a volume's feature maps, cached on its factor handle."""
+        fac = volume_factors(volume)
+        cached = fac._rank1_tables
         if cached is not None and cached[0] is self:
             return cached[1], cached[2]
-        _, ref, tgt = volume._dv_factors
-        gl, gr = self.table_l(ref), self.table_r(tgt)
-        volume._dv_rank1_tables = (self, gl, gr)
+        gl, gr = self.table_l(fac.ref), self.table_r(fac.tgt)
+        fac._rank1_tables = (self, gl, gr)
         return gl, gr
 
-    def __call__(self, volume: torch.Tensor, noise01: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def __call__(self, volume, noise01: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``noise01`` None: the unfiltered volume (the origin network's first aggregation layer, acv.py)."""
-        p_att = volume._dv_factors[0]
+        p_att = volume_factors(volume).p_att
         b, d, h, w = p_att.shape
         gl, gr = self.tables(volume)
         out = torch.empty((b, self.cout, d, h, w), dtype=torch.float32, device=p_att.device)

@@ -57,6 +57,10 @@ int dv_concat_volume_f32(const float* ref, const float* tgt, float* out,
  * fused.  att [B,1,D,H,W] logits -> out [B,2C,D,H,W]. */
 int dv_concat_attn_volume_f32(const float* ref, const float* tgt, const float* att, float* out,
                               int B, int C, int H, int W, int D, dv_stream_t stream);
+/* The same product from the softmax already taken (p [B,D,H,W] of dv_softmax_d_f32; identical bits): what
+ * AttentionConcatVolume.tensor() runs when something other than the rank-1 layer wants the tensor of acv_ddim.py:390. */
+int dv_concat_prob_volume_f32(const float* ref, const float* tgt, const float* p, float* out,
+                              int B, int C, int H, int W, int D, dv_stream_t stream);
 
 /* ---- the first aggregation layer of a DiffuVolume step on its factored input --------------------------------
  * SceneFlow/models/acv_ddim.py:254-262 feeds `volume * noise` to dres0[0] (convbn_3d(64,32,3,1,1) + ReLU, :200-203)

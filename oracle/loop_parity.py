@@ -109,6 +109,38 @@ def teacher_forced(model, trace, vol_d, used_d, used, gt, **step_kw) -> List[Dic
 
 
 @torch.no_grad()
+def pcw_teacher_forced_split(model, trace, vol_d, used_d, features_left, features_right) -> List[Dict]:
+    """KITTI12 step taken apart at the one hard decision inside it.  The per-step disparity of this flavour is
+    ``refine(pred3)`` (pwcnet_ddim.py:486-502), and ``warp`` inside the refinement zeroes the warped feature wherever
+    ``grid_sample(ones) < 0.999`` (submodule.py:170-174): a pixel whose sampling position x - pred3 lies within rounding
+    of the image border takes the other branch in two correct evaluations, and the 9 dilated 2-D layers spread that one
+    flipped feature vector over a +-61-pixel neighbourhood (measured at 1248x384: one flipped pixel -> 2 % of the image
+    beyond 1e-3 px, max 0.1 px).  So, per step of ``trace`` and from the ORACLE's state:
+      pred3            HIP 3-D stack + regression vs the oracle's pred3                      (function comparison)
+      refine           HIP refinement FROM THE ORACLE'S pred3 vs the oracle's disparity      (function comparison)
+      warp_mask_flips  pixels where the validity decision differs between the two pred3's
+      disp             the composite step (raw figures; within the bars whenever warp_mask_flips == 0)"""
+    from . import pcw_oracle as P
+    from diffuvolume_amd.submodule import upsample_softmax_regress
+    dev = vol_d.device
+    out = []
+    for i, r in enumerate(trace):
+        mask = r["mask_in"].to(dev).clone()
+        eps = None if r["eps"] is None else r["eps"].to(dev)
+        fill = None if r["fill"] is None else r["fill"].to(dev)
+        disp, unc, xs, xn, cost = model.ddim_step(i, vol_d, used_d, r["img"].to(dev), mask, None, eps, fill,
+                                                  features_left, features_right, want_cost=True)
+        pred3_h, _ = upsample_softmax_regress(cost, want_uncertainty=False, align_corners=True)
+        refined = model._refine(r["pred3"].to(dev), features_left, features_right).cpu()
+        pred3_h = pred3_h.cpu()
+        flips = P.warp_valid_mask(pred3_h.unsqueeze(1)) != P.warp_valid_mask(r["pred3"].unsqueeze(1))
+        s = {"step": i + 1, "pred3": _stats((pred3_h - r["pred3"]).abs()), "refine": _stats((refined - r["disp"]).abs()),
+             "disp": _stats((disp.cpu() - r["disp"]).abs()), "warp_mask_flips": int(flips.sum())}
+        out.append(s)
+    return out
+
+
+@torch.no_grad()
 def teacher_forced_vs_fp64(model, orc32, orc64, trace, vol, vol_d, used_d, oracle_args=(), **step_kw) -> List[Dict]:
     """Triangulation against a float64 evaluation of the reference's function.  For every step of ``trace`` (the fp32
     oracle's run), from the SAME entering state: disparity of the HIP path, of the fp32 oracle and of the oracle with

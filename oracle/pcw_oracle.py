@@ -71,6 +71,20 @@ def warp(x: Tensor, disp: Tensor) -> Tensor:
     return out * mask
 
 
+def warp_valid_mask(disp: Tensor) -> Tensor:
+    """The validity mask of ``warp`` alone (submodule.py:170-174): 1 where `grid_sample(ones)` >= 0.999, else 0 -- a HARD
+    threshold on a continuous function of the disparity, i.e. a decision two correct evaluations can take differently
+    at a pixel whose sampling position lies within rounding of the image border.  disp [B,1,H,W] -> [B,H,W] bool."""
+    b, _, h, w = disp.shape
+    xx = torch.arange(0, w).view(1, -1).repeat(h, 1).view(1, 1, h, w).repeat(b, 1, 1, 1).to(disp.dtype)
+    yy = torch.arange(0, h).view(-1, 1).repeat(1, w).view(1, 1, h, w).repeat(b, 1, 1, 1).to(disp.dtype)
+    vgrid = torch.cat((xx - disp, yy), 1)
+    vgrid[:, 0] = 2.0 * vgrid[:, 0].clone() / max(w - 1, 1) - 1.0
+    vgrid[:, 1] = 2.0 * vgrid[:, 1].clone() / max(h - 1, 1) - 1.0
+    mask = F.grid_sample(torch.ones_like(disp), vgrid.permute(0, 2, 3, 1))
+    return (mask >= 0.999)[:, 0]
+
+
 def correlation_pm(ref: Tensor, tgt: Tensor, maxdisp: int) -> Tensor:
     """build_corrleation_volume(ref, tgt, maxdisp, 1).squeeze(1) (submodule.py:121-135)."""
     b, c, h, w = ref.shape
@@ -164,6 +178,7 @@ class PCWDiffusionOracle:
         n01 = ((torch.clamp(x_t + shift, -self.scale, self.scale) / self.scale) + 1) / 2
         cost = self.aggregate(volume * n01.unsqueeze(1).float())
         pred3, prob = A.upsample_softmax_regress(cost, self.maxdisp, align_corners=True)
+        self.last_pred3 = pred3                 # (kept for the parity bookkeeping: the input of the 2-D refinement)
         disp = self.refine(pred3, fl, fr)
         dn = torch.clamp(disp, 0, self.maxdisp - 1).unsqueeze(1)
         hh, ww = dn.shape[-2:]
@@ -192,6 +207,7 @@ class PCWDiffusionOracle:
             rec = None
             if trace is not None:
                 rec = {"time": time, "time_next": time_next, "img": img, "mask_in": mask, "disp": disp, "unc": unc,
+                       "pred3": self.last_pred3,
                        "x_start": x_start, "eps": None, "fill": None, "img_next": None, "mask_out": None}
                 trace.append(rec)
             if time_next >= 0:

@@ -52,3 +52,19 @@ def acv_state_dict():
     from diffuvolume_amd.acv_ddim import ACVNet_DDIM
     from diffuvolume_amd.synth import synth_state_dict
     return synth_state_dict(ACVNet_DDIM(192, False, False).state_dict(), seed=1, logit_gain=8.0)
+
+
+def conditioned_pcw_state_dict(name):
+    """The CONDITIONED KITTI12 weights of oracle/calibrate.py: the synthetic PWCNet_ddim state dict (seed 2) with the
+    classifier gain / refinement-head factor the fixture names and the BatchNorm statistics stored in
+    tests/golden/<name>.npz (written by oracle/make_golden_pcw_conditioned.py)."""
+    from diffuvolume_amd.pwcnet_ddim import PWCNet_ddim
+    from diffuvolume_amd.synth import synth_state_dict
+    from oracle import calibrate as C
+    g = load_golden(name)
+    sd = synth_state_dict(PWCNet_ddim(192, True).state_dict(), seed=2, logit_gain=float(g["gain"]),
+                          scale={"refinenet3.conv8.weight": float(g["head"])})
+    stats = C.unpack(g["bn_keys"], g["bn_vals"], g["bn_lens"])
+    assert set(stats) <= set(sd)
+    sd.update(stats)
+    return sd, g

@@ -30,6 +30,40 @@ def test_self_launch_two_ranks():
     assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["launcher"] == "self" and line["global_batch"] == 16
 
 
+def test_self_launch_eight_ranks():
+    """The N = 8 launch the driver's scaling run uses (BASELINE configs 3 and 5), over gloo on the CPU: eight ranks meet,
+    the collective sees all eight, the global batch is 8 pairs per rank.  The subprocess timeout is the bound."""
+    r = _run(["--gpus", "8", "--dry-run"], timeout=300)
+    assert r.returncode == 0, r.stderr
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 8 and line["ranks"] == 8 and line["launcher"] == "self" and line["global_batch"] == 64
+
+
+def test_a_bare_world_size_does_not_start_a_process_group():
+    """WORLD_SIZE=1 exported by a scheduler (no RANK / LOCAL_RANK / MASTER_PORT) is not a launcher."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", ROOT / "bench.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "DV_BENCH_SELF_LAUNCHED")
+    old = {k: os.environ.get(k) for k in keys}
+    try:
+        for k in keys:
+            os.environ.pop(k, None)
+        os.environ["WORLD_SIZE"] = "1"
+        assert not mod.under_launcher() and mod.launcher_label() == "single"
+        os.environ.update(RANK="0", LOCAL_RANK="0", MASTER_PORT="29999")
+        assert mod.under_launcher() and mod.launcher_label() == "env"
+        os.environ["TORCHELASTIC_RUN_ID"] = "x"
+        assert mod.launcher_label() == "torchrun"
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_under_torchrun_two_ranks():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29653", str(ROOT / "bench.py"), "--gpus", "2",

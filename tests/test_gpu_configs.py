@@ -22,14 +22,24 @@ def rel(a, b):
     return float((a.cpu().double() - b.double()).abs().max() / b.double().abs().max().clamp(min=1e-30))
 
 
-@pytest.fixture(scope="module")
-def setup():
+_SETUPS = {}
+
+
+def _setup(kind):
+    """kind 'diagnostic': the synthetic weights with random BatchNorm statistics and the calibration factors of the
+    pcw_forward_eval fixture (untrained residual stacks otherwise reach 1e9; logits still reach +-2600).  kind
+    'conditioned': oracle/calibrate.py -- BatchNorm buffers = statistics of pair 0 of this very batch (stored in
+    tests/golden/pcw_conditioned_config4.npz), classifier gain 0.5, refinement head x 0.2."""
+    if kind in _SETUPS:
+        return _SETUPS[kind]
     from diffuvolume_amd.pwcnet_ddim import PWCNet_ddim
-    # the calibration factors of the pcw_forward_eval fixture (untrained residual stacks otherwise reach 1e9)
-    from conftest import load_golden
-    g = load_golden("pcw_forward_eval")
-    scale = {str(k): float(v) for k, v in zip(g["scale_keys"].tolist(), g["scale_vals"].tolist())}
-    sd = synth_state_dict(PWCNet_ddim(192, True).state_dict(), seed=2, logit_gain=8.0, scale=scale)
+    from conftest import conditioned_pcw_state_dict, load_golden
+    if kind == "conditioned":
+        sd, _ = conditioned_pcw_state_dict("pcw_conditioned_config4")
+    else:
+        g = load_golden("pcw_forward_eval")
+        scale = {str(k): float(v) for k, v in zip(g["scale_keys"].tolist(), g["scale_vals"].tolist())}
+        sd = synth_state_dict(PWCNet_ddim(192, True).state_dict(), seed=2, logit_gain=8.0, scale=scale)
     m = PWCNet_ddim(192, True)
     m.load_state_dict(sd, strict=True)
     m = m.to(DEV).eval()
@@ -37,7 +47,13 @@ def setup():
     with torch.no_grad():
         fl = m.feature_extraction(batch["left"])
         fr = m.feature_extraction(batch["right"])
-    return m, sd, batch, fl, fr
+    _SETUPS[kind] = (m, sd, batch, fl, fr)
+    return _SETUPS[kind]
+
+
+@pytest.fixture(scope="module")
+def setup():
+    return _setup("diagnostic")
 
 
 def one(feats, i):
@@ -57,8 +73,22 @@ def test_builders_at_kitti_widths(setup):
         assert torch.equal(cat[:1].cpu(), A.build_concat_volume(cl[:1].cpu(), cr[:1].cpu(), 192 // div, zero_left=True))
 
 
-def test_fused_volume_and_loop_vs_oracle(setup):
-    m, sd, batch, fl, fr = setup
+@pytest.mark.parametrize("kind", ["conditioned", "diagnostic"])
+def test_fused_volume_and_loop_vs_oracle(kind):
+    """Pair 0 at 1248x384 against the oracle: the fused volume, every DDIM step from the oracle's state, the free run.
+
+    'conditioned' (verdict r3 #1b): the contract as written, RAW -- |d disp| <= 1e-3 px on 99.9 % of all 479 232
+    pixels and |dEPE| < 1e-4 per teacher-forced step (all inputs the oracle's) and, when no hard decision of the
+    reference function came out differently, for the free run on HIP's own volume.
+    'diagnostic': the unconditioned network of rounds 1-3 (logits +-2600; the fp32 ORACLE is beyond 1e-3 px of its own
+    float64 evaluation on 15-19 % of the pixels, profiles/r03_parity_config4_fp64_triangulation.json): figures
+    recorded, EPE bar and a defect bound (a real defect shows up at 1e-2..1 px) asserted; its float64 triangulation
+    runs under DV_FULL_PARITY=1."""
+    import json
+    import os
+    m, sd, batch, fl, fr = _setup(kind)
+    raw = kind == "conditioned"
+    full = os.environ.get("DV_FULL_PARITY") == "1"
     fl0, fr0 = one(fl, 0), one(fr, 0)
     with torch.no_grad():
         vol_d = m.fused_volume({k: v[:1] for k, v in fl.items()}, {k: v[:1] for k, v in fr.items()})
@@ -70,44 +100,68 @@ def test_fused_volume_and_loop_vs_oracle(setup):
     orc = P.PCWDiffusionOracle(sd)
     final_o, stack_o, trace = LP.oracle_trajectory(orc, vol, used, asd.cpu(), 11, fl0, fr0)
     dl, dr = {k: v[:1] for k, v in fl.items()}, {k: v[:1] for k, v in fr.items()}
-    tf = LP.teacher_forced(m, trace, vol_d, batch["used"][:1], used, gt, features_left=dl, features_right=dr)
+    # teacher forced = every input of the step is the oracle's, the volume included (its own parity is the assertion
+    # above); the free run is the chain on HIP's own volume
+    vol_in = vol.to(DEV) if raw else vol_d
+    tf = LP.teacher_forced(m, trace, vol_in, batch["used"][:1], used, gt, features_left=dl, features_right=dr)
     fr_ = LP.free_run(m, trace, stack_o, final_o, vol_d, batch["used"][:1], asd, gt, 11, dl, dr)
-    print({"teacher_forced": tf, "free_run": fr_})
-    # Per step from the oracle's state: the contract's EPE bar, and the mean pixel distance below the pixel bar.  The
-    # share of pixels beyond 1e-3 px is ~2 % here (max 0.1 px): the per-step disparity of this flavour is the output of
-    # the untrained dilated 2-D refinement stack (warp -> +-24 correlation -> 9 conv layers), which amplifies the
-    # 1e-4-px agreement of the 3-D part; against a float64 evaluation the HIP step is as close as the fp32 oracle is
-    # (tests/test_gpu_pcw.py::test_ddim_sample_golden_and_float64, asserted per step), i.e. this is the spread of two
-    # correct fp32 evaluations, bounded here so that a real defect (which shows up at 1e-2..1 px) cannot hide.
-    for s in tf:
+    keys = ("step", "mean_abs_px", "frac_gt_1e-3", "max_px", "epe_delta", "unc_mean_px", "flips_mask_zero")
+    report = {"network": kind, "teacher_forced": [{k: s.get(k) for k in keys} for s in tf],
+              "free_run": [{k: s.get(k) for k in keys} for s in fr_["steps"]], "free_run_final": fr_["final"]}
+    print(json.dumps(report))
+    flips = sum(s["flips_mask_zero"] for s in fr_["steps"])
+    # The step taken apart at the one hard decision inside it (the 0.999 validity threshold of `warp`, submodule.py:
+    # 170-174; oracle/loop_parity.py::pcw_teacher_forced_split): the 3-D stack + regression and the 2-D refinement are each
+    # held to the RAW bars as functions of the oracle's inputs; the composite step is held to them whenever the two
+    # validity masks agree (one flipped pixel moves 2 % of this image by up to 0.1 px through the +-61-pixel receptive
+    # field of the dilated stack -- in the reference exactly as here).
+    split = LP.pcw_teacher_forced_split(m, trace, vol_in, batch["used"][:1], dl, dr) if raw else []
+    report["teacher_forced_split"] = split
+    print(json.dumps(split))
+    for s in split:
+        assert s["pred3"]["frac_gt_1e-3"] <= LP.BAR_FRAC and s["pred3"]["mean_abs_px"] < 2e-4, s
+        assert s["refine"]["frac_gt_1e-3"] <= LP.BAR_FRAC and s["refine"]["mean_abs_px"] < 1e-4, s
+    warp_flips = sum(s["warp_mask_flips"] for s in split)
+    for i, s in enumerate(tf):
         assert s["epe_delta"] < LP.BAR_EPE, s
         assert s["mean_abs_px"] < LP.BAR_PX, s
-        assert s["frac_gt_1e-3"] < 0.05 and s["max_px"] < 0.5, s
-    # the same steps against a float64 evaluation of the reference's function (weights and activations, 3-D stack and 2-D
-    # refinement): RAW figures, no scaling -- the HIP step is no further from the float64 value than the fp32 reference
-    # path itself is (share of pixels beyond 1e-3 px and mean distance, each within 1.5x + a floor), which is the
-    # statement the 2 % above cannot make: two fp32 evaluations of this untrained refinement stack differ by their sum
-    sd64 = {k: (v.double() if v.is_floating_point() and not k.startswith("time_embedding") else v) for k, v in sd.items()}
-    f64 = lambda feats: {k: v.double() for k, v in feats.items()}
-    # (default: the first step only -- the float64 oracle of this flavour costs ~40 s of CPU per step; DV_FULL_PARITY=1: all
-    # three, which is how profiles/r03_parity_config4_fp64_triangulation.json was made)
-    full = __import__("os").environ.get("DV_FULL_PARITY") == "1"
-    tri = LP.teacher_forced_vs_fp64(m, orc, P.PCWDiffusionOracle(sd64), trace if full else trace[:1], vol, vol_d, batch["used"][:1],
-                                    oracle_args=(f64(fl0), f64(fr0)), features_left=dl, features_right=dr)
-    import json
-    import os
+        if raw and split[i]["warp_mask_flips"] == 0:
+            assert s["frac_gt_1e-3"] <= LP.BAR_FRAC, s            # the contract's pixel figure: all pixels, unscaled
+        elif raw:      # a validity decision differs: the disturbance is bounded by its receptive field (123 x 123 pixels)
+            assert s["frac_gt_1e-3"] <= split[i]["warp_mask_flips"] * 123 * 123 / float(H * W) + LP.BAR_FRAC and s["max_px"] < 0.5, s
+        else:
+            assert s["frac_gt_1e-3"] < 0.05 and s["max_px"] < 0.5, s
+    # the same steps against a float64 evaluation of the reference's function (weights and activations, 3-D stack and
+    # 2-D refinement), RAW figures: HIP no further from float64 than the fp32 reference path is (DV_FULL_PARITY=1: the
+    # float64 oracle costs ~40 s of CPU per step; the conditioned network does not need the triangulation -- it meets
+    # the bars against the fp32 oracle directly)
+    tri = None
+    if full:
+        sd64 = {k: (v.double() if v.is_floating_point() and not k.startswith("time_embedding") else v) for k, v in sd.items()}
+        f64 = lambda feats: {k: v.double() for k, v in feats.items()}
+        tri = LP.teacher_forced_vs_fp64(m, orc, P.PCWDiffusionOracle(sd64), trace, vol, vol_in,
+                                        batch["used"][:1], oracle_args=(f64(fl0), f64(fr0)), features_left=dl,
+                                        features_right=dr)
+        print(json.dumps(tri))
+        for s in tri:
+            h, o = s["hip_vs_fp64"], s["oracle32_vs_fp64"]
+            assert h["mean_abs_px"] <= 1.5 * o["mean_abs_px"] + 2e-5, s
+            assert h["frac_gt_1e-3"] <= 1.5 * o["frac_gt_1e-3"] + 1e-3, s
+    if raw:    # the chain on HIP's own volume: its validity decisions against the oracle's
+        chain = LP.pcw_teacher_forced_split(m, trace, vol_d, batch["used"][:1], dl, dr)
+        warp_flips += sum(s["warp_mask_flips"] for s in chain)
+        report["chain_on_hip_volume"] = chain
     os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/parity_config4_fp64_triangulation.json", "w") as f:
-        json.dump({"teacher_forced": tf, "fp64_triangulation": tri}, f, indent=1)
-    print(json.dumps(tri))
-    for s in tri:
-        h, o = s["hip_vs_fp64"], s["oracle32_vs_fp64"]
-        assert h["mean_abs_px"] <= 1.5 * o["mean_abs_px"] + 2e-5, s
-        assert h["frac_gt_1e-3"] <= 1.5 * o["frac_gt_1e-3"] + 1e-3, s
-    if sum(s["flips_mask_zero"] for s in fr_["steps"]) == 0:
+    with open(f"gpurun_out/parity_config4_{kind}.json", "w") as f:
+        json.dump(dict(report, fp64_triangulation=tri, warp_mask_flips=warp_flips), f, indent=1)
+    if flips == 0:
         assert fr_["final"]["epe_delta"] < LP.BAR_EPE, fr_["final"]
+        if raw and warp_flips == 0:
+            assert fr_["final"]["frac_gt_1e-3"] <= LP.BAR_FRAC, fr_["final"]
         for s in fr_["steps"]:
             assert s["epe_delta"] < LP.BAR_EPE and s["mean_abs_px"] < 2e-3, s
+            if raw and warp_flips == 0:
+                assert s["frac_gt_1e-3"] <= LP.BAR_FRAC, s
 
 
 def test_batch_of_four_and_shard_invariance(setup):

@@ -190,6 +190,56 @@ def test_ddim_loop_20_steps_teacher_forced_vs_oracle():
     assert float(d.median()) < 2e-3, (float(d.median()), float(d.mean()))
 
 
+def test_ddim_step_teacher_forced_at_config5_size():
+    """One DDIM step of BASELINE config 5 at its real geometry -- 1248x384 (quarter resolution 96 x 312: 4.875 tiles of
+    64 columns), 32 GRU iterations through the real update block, the filtered geometry lookup at every iteration --
+    against oracle/igev_oracle.py (igev_stereo_ddim.py:226-292), at the contract's raw bars on all 479 232 pixels:
+    |d disp| <= 1e-3 px on 99.9 % of them, |EPE_hip - EPE_oracle| < 1e-4.  Steps t = 999 (float32 state) and t = 949
+    (a float64 state, hidden states carried over).  ~1 min of host CPU."""
+    from diffuvolume_amd.geometry_ddim import Combined_Geo_Encoding_Volume
+    from diffuvolume_amd.igev_stereo_ddim import DynamicHead180, IGEVDiffusionLoop
+    from diffuvolume_amd.synth import synth_state_dict, toy_upsample_disp
+    from diffuvolume_amd.update import BasicMultiUpdateBlock
+    b, h, w, steps, iters = 1, 96, 312, 20, 32
+    cof = (0.6,) + (0.0,) * (steps - 2) + (0.1, 0.3)
+    sd = update_state_dict(161)
+    sd["disp_head.conv2.weight"] = sd["disp_head.conv2.weight"] * 0.05      # keep the per-iteration step ~1 bin
+    m = BasicMultiUpdateBlock(ARGS, hidden_dims=[128, 128, 128])
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    head = DynamicHead180()
+    head.load_state_dict(synth_state_dict(head.state_dict(), seed=162), strict=True)
+    head = head.eval()
+    net, inp, _, _ = update_inputs(163, b, h, w)
+    geo = torch.randn(b, 8, 48, h, w, generator=_gen(164, "geo"))
+    f1, f2 = torch.randn(b, 16, h, w, generator=_gen(164, "f1")), torch.randn(b, 16, h, w, generator=_gen(164, "f2"))
+    init = torch.rand(b, 1, h, w, generator=_gen(164, "init")) * 40
+    used = torch.nn.functional.interpolate(init * 4, scale_factor=4, mode="bilinear") + 1.5
+    u2 = used.reshape(b, 4 * h, 4 * w)
+    orc = I.IGEVLoopOracle(head.state_dict(), lambda n, i, c, f, **kw: I.update_block(sd, n, i, c, f), toy_upsample_disp,
+                           geo, f1, f2, sampling_timesteps=steps, cof=cof, net_list=net, inp_list=inp)
+    geo_fn = Combined_Geo_Encoding_Volume(dev(f1), dev(f2), dev(geo), radius=4, num_levels=2)
+    loop = IGEVDiffusionLoop(head.to(DEV), m, toy_upsample_disp, n_gru_layers=3, slow_fast_gru=False,
+                             sampling_timesteps=steps, ensemble_cof=cof)
+    dinp = [[dev(x) for x in l] for l in inp]
+    coords1 = init
+    for time, dtype in ((999, torch.float32), (949, torch.float64)):
+        x_t = torch.randn(b, 48, h, w, generator=_gen(165, f"xt{time}")).to(dtype)
+        t = torch.full((b,), time, dtype=torch.long)
+        nets_in = list(orc.net_list)
+        _, xs_ref, pred_ref, c1_ref = orc.model_predictions(init, coords1, iters, x_t, t)
+        _, xs, pred, c1 = loop.model_predictions(dev(init), dev(coords1), None, iters, [dev(x) for x in nets_in], dinp,
+                                                 geo_fn, dev(x_t), dev(t), None)
+        d = (pred.cpu() - pred_ref).abs().reshape(b, 4 * h, 4 * w)
+        frac = float((d > 1e-3).float().mean())
+        epe = abs(float((pred.cpu().reshape(u2.shape) - u2).abs().mean()) - float((pred_ref.reshape(u2.shape) - u2).abs().mean()))
+        print(f"config-5 size, t = {time}: mean {float(d.mean()):.2e} px, max {float(d.max()):.2e} px, "
+              f"share beyond 1e-3 px {frac:.2e}, |dEPE| {epe:.2e}")
+        assert frac <= 1e-3 and epe < 1e-4, (time, frac, epe, float(d.max()))
+        torch.testing.assert_close(c1.cpu(), c1_ref, atol=1e-3, rtol=1e-5)
+        coords1 = c1_ref
+
+
 @pytest.mark.parametrize("shape", [(2, 5, 24, 78), (1, 3, 7, 9), (1, 2, 1, 5), (2, 4, 12, 39)])
 def test_update_glue_kernels_vs_torch(shape):
     """csrc/update_glue.hip: `pool2x`, `interp` (bilinear, align_corners=True) and the single-input-channel 7x7 `convd1`

@@ -500,7 +500,8 @@ def test_forward_golden(model, acv_state_dict):
         del model.ddim_sample
     d = (pred.cpu() - g["pred"]).abs()
     assert float(d.median()) < 1e-4, float(d.median())
-    rep = _assert_loop_contract(model, acv_state_dict, seen["vol"].cpu(), batch["used"], seen["x_T"].cpu(),
+    vol = seen["vol"].tensor() if hasattr(seen["vol"], "tensor") else seen["vol"]     # forward() passes the factor handle
+    rep = _assert_loop_contract(model, acv_state_dict, vol.cpu(), batch["used"], seen["x_T"].cpu(),
                                 g["tape_seed"], gt=batch["gt"])
     if rep["flips"] == 0:                      # no decision differs: the whole forward meets the contract vs the reference
         assert float((d > 1e-3).float().mean()) <= 1e-3

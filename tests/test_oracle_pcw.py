@@ -52,3 +52,34 @@ def test_ddim_sample(pcw_sd):
     for i in range(1, 4):
         assert float(d[i].median()) < 1e-4, (i, float(d[i].median()))
     assert float((final - g["final"]).abs().mean()) < 1e-3
+
+
+def test_conditioned_network_at_the_raw_bars():
+    """The conditioned network (oracle/calibrate.py: BatchNorm buffers = statistics of the data, classifier gain 0.5,
+    refinement head x 0.2): the oracle meets the IMPORTED REFERENCE's outputs at the contract's raw bars on every
+    step, and a float64 evaluation of the oracle shows the network is well conditioned (fp32 within 1e-3 px of float64
+    on every pixel) -- which is what entitles the GPU tests to assert the raw bars on it."""
+    from conftest import conditioned_pcw_state_dict
+    from oracle import acv_oracle as A
+    sd, g = conditioned_pcw_state_dict("pcw_conditioned_fixture")
+    vol, fl, fr = _inputs(g["seed"])
+    orc = P.PCWDiffusionOracle(sd)
+    pn, xs, disp, prob = orc.model_predictions(vol, g["x_t"], g["t"], fl, fr)
+    d = (disp - g["disp"]).abs()
+    assert float((d > 1e-3).float().mean()) <= 1e-3 and float(d.mean()) < 1e-4, (float(d.mean()), float(d.max()))
+    assert float((A.disparity_uncertainty(disp, prob) - g["unc"]).abs().mean()) < 1e-3
+    final, stack = orc.ddim_sample(vol, g["used"], g["asd"], fl, fr, NoiseTape(g["tape_seed"]))
+    for i in range(1, 4):
+        di = (stack[i] - g["stack"][i]).abs()
+        assert float((di > 1e-3).float().mean()) <= 1e-3, (i, float(di.mean()), float(di.max()))
+        assert abs(float((stack[i] - g["used"]).abs().mean()) - float((g["stack"][i] - g["used"]).abs().mean())) < 1e-4
+    assert float(((final - g["final"]).abs() > 1e-3).float().mean()) <= 1e-3
+    # conditioning: float64 weights and activations
+    sd64 = {k: (v.double() if v.is_floating_point() and not k.startswith("time_embedding") else v) for k, v in sd.items()}
+    f64 = lambda feats: {k: v.double() for k, v in feats.items()}
+    d64 = P.PCWDiffusionOracle(sd64).model_predictions(vol.double(), g["x_t"].double(), g["t"], f64(fl), f64(fr))[2]
+    e = (disp.double() - d64).abs()
+    assert float(e.max()) < 1e-3 and float(e.mean()) < 1e-4, (float(e.mean()), float(e.max()))
+    # the refinement head is not idle on this network: it moves the disparity by O(1) px
+    pred3 = A.upsample_softmax_regress(orc.aggregate(vol * (((torch.clamp(g["x_t"] + A.time_shift(g["t"], sd)[:, :, None, None], -1, 1)) + 1) / 2).unsqueeze(1)), 192, align_corners=True)[0]
+    assert float((disp - pred3).abs().mean()) > 0.5

@@ -75,6 +75,7 @@ SIGNATURES = {
     "dv_feature_gate_f32": (c_int, [P, P, P, I, I, I, I, I, P]),
     "dv_deconv3d_k3s2_redir_f32": (c_int, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "dv_patch_volume_f32": (c_int, [P, P, P, P, P, I, I, I, I, I, P]),
+    "dv_patch_volume_runs_f32": (c_int, [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P]),
     "dv_window_attn3d_f32": (c_int, [P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "dv_upsample_softmax_regress_f32": (c_int, [P, P, P, I, I, I, I, I, P]),
     "dv_upsample_softmax_uncertainty_f32": (c_int, [P, P, P, I, I, I, I, I, P]),

@@ -11,6 +11,7 @@ runs on the MI355X or raises.
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Optional, Tuple
 
 import torch
@@ -929,19 +930,38 @@ def refine_inputs(left: torch.Tensor, right: torch.Tensor, disp: torch.Tensor, d
 
 def patch_volume(gwc: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, dilation: torch.Tensor) -> torch.Tensor:
     """`patch` followed by `patch_l1/l2/l3` (acv_ddim.py:377-381): two per-channel (1,3,3) stencils in one pass.
-    gwc [B,G,D,H,W]; w1, w2 [G,9] float32; dilation [G] int32 (1..3)."""
+    gwc [B,G,D,H,W]; w1, w2 [G,9] float32; dilation [G] int32 (1..3).  The dilation table is turned into runs of
+    consecutive groups on the host ONCE per tensor object (cached on it: a device tensor costs one synchronising read
+    the first time) so that the launcher can pick the dilation-specialised 16-byte kernels."""
     gwc = _dev_f32(gwc, "gwc")
     b, g, d, h, w = gwc.shape
     w1, w2 = _dev_f32(w1, "w1"), _dev_f32(w2, "w2")
     if tuple(w1.shape) != (g, 9) or tuple(w2.shape) != (g, 9) or dilation.numel() != g or dilation.dtype != torch.int32:
         raise RuntimeError("w1 / w2 must be [G,9] and dilation [G] int32")
+    runs = getattr(dilation, "_dv_runs", None)
+    if runs is None or runs[0] != dilation._version:
+        vals, r = dilation.detach().cpu().tolist(), []
+        for i, v in enumerate(vals):
+            if r and r[-1][2] == v:
+                r[-1][1] += 1
+            else:
+                r.append([i, 1, v])
+        arr = lambda k: (ctypes.c_int * len(r))(*[x[k] for x in r])
+        runs = (dilation._version, len(r), arr(0), arr(1), arr(2), all(1 <= x[2] <= 3 for x in r))
+        dilation._dv_runs = runs
     out = torch.empty_like(gwc)
     lib = _lib.load()
+    dil_dev = dilation.contiguous()
     with torch.cuda.device(gwc.device):
-        timed("patch_volume", 36.0 * gwc.numel(), 8.0 * gwc.numel(),
-              lambda: _lib.check(lib.dv_patch_volume_f32(gwc.data_ptr(), w1.data_ptr(), w2.data_ptr(),
-                                                         dilation.contiguous().data_ptr(), out.data_ptr(), b, g, d, h, w,
-                                                         _lib.stream_ptr()), "dv_patch_volume_f32"))
+        if runs[5]:
+            call = lambda: _lib.check(lib.dv_patch_volume_runs_f32(gwc.data_ptr(), w1.data_ptr(), w2.data_ptr(), dil_dev.data_ptr(),
+                                                                   out.data_ptr(), b, g, d, h, w, runs[1], runs[2], runs[3],
+                                                                   runs[4], _lib.stream_ptr()), "dv_patch_volume_runs_f32")
+        else:
+            call = lambda: _lib.check(lib.dv_patch_volume_f32(gwc.data_ptr(), w1.data_ptr(), w2.data_ptr(), dil_dev.data_ptr(),
+                                                              out.data_ptr(), b, g, d, h, w, _lib.stream_ptr()),
+                                      "dv_patch_volume_f32")
+        timed("patch_volume", 36.0 * gwc.numel(), 8.0 * gwc.numel(), call)
     return out
 
 

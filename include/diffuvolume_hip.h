@@ -257,6 +257,12 @@ int dv_deconv3d_k3s2_redir_f32(const float* in, const float* wpacked, const floa
  * dilation [G] (int32, 1..3).  All pointers on the device. */
 int dv_patch_volume_f32(const float* gwc, const float* w1, const float* w2, const int* dilation, float* out,
                         int B, int G, int D, int H, int W, dv_stream_t stream);
+/* The same pass with the dilation given as host-side runs of consecutive groups (run r: groups run_g0[r] ..
+ * run_g0[r] + run_ng[r] - 1 at dilation run_dil[r]; the runs tile 0..G-1 in order): the 16-byte fast path needs the
+ * dilation at launch time.  `dilation_dev` (device, [G]) serves the element-wise kernel when W % 4 != 0. */
+int dv_patch_volume_runs_f32(const float* gwc, const float* w1, const float* w2, const int* dilation_dev, float* out,
+                             int B, int G, int D, int H, int W, int nruns, const int* run_g0, const int* run_ng,
+                             const int* run_dil, dv_stream_t stream);
 
 /* attention_block.forward: SceneFlow/models/submodule.py:398-429 -- 4x4x4 window
  * multi-head self-attention (heads x C/heads), qkv Linear(C,3C)+bias, softmax,

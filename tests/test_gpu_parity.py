@@ -394,7 +394,7 @@ def _assert_loop_contract(model, sd, vol, used, x_T, seed, gt=None, traj_epe=1e-
     reference itself is confident (uncertainty < 3 px, acv_ddim.py:330) and scales with the spread of the
     distribution elsewhere (`frac_gt_bar`, loop_parity._stats): with these untrained weights the soft-argmax sits on
     a ~50 px wide distribution and amplifies the last bit of the fp32 cost 17x more than a trained network does
-    (measured split: tools/diag/diag_split.py).  EPE is asserted unscaled.  Returns the report."""
+    (measured split: profiles/attic/diag/diag_split.py).  EPE is asserted unscaled.  Returns the report."""
     from oracle import loop_parity as LP
     gt = used if gt is None else gt                     # fixtures without ground truth: EPE against `used`
     orc = O.ACVDiffusionOracle(sd)
@@ -817,9 +817,12 @@ def test_feature_cnn_matches_the_reference_class():
     assert rel_err(y, g["acv_gwc_feature"]) < 2e-5
 
 
-@pytest.mark.parametrize("shape", [(1, 40, 3, 20, 140), (2, 40, 2, 33, 50)])
+@pytest.mark.parametrize("shape", [(1, 40, 3, 20, 140), (2, 40, 2, 33, 50), (1, 40, 1, 128, 240), (2, 40, 2, 17, 12),
+                                   (1, 40, 2, 16, 128)])
 def test_patch_volume_vs_pytorch_depthwise(shape):
-    """patch + patch_l1/l2/l3 (acv_ddim.py:181-188, :377-381) fused, vs the nn.Conv3d modules themselves."""
+    """patch + patch_l1/l2/l3 (acv_ddim.py:181-188, :377-381) fused, vs the nn.Conv3d modules themselves: widths on the
+    16-byte path (multiples of 4: one partial 128-column tile, the bench plane, a plane narrower than the halo, exactly
+    one tile) and the element-wise path (W = 50)."""
     from diffuvolume_amd.submodule import patch_volume
     g = _gen(81, str(shape))
     x = torch.randn(*shape, generator=g)
@@ -835,6 +838,13 @@ def test_patch_volume_vs_pytorch_depthwise(shape):
     dil = torch.tensor([1] * 8 + [2] * 16 + [3] * 16, dtype=torch.int32)
     out = patch_volume(dev(x), dev(w1), dev(w2), dev(dil))
     torch.testing.assert_close(out.cpu(), ref, atol=2e-5, rtol=1e-5)
+    # the element-wise kernel through the device-table entry point gives the same function
+    out2 = torch.empty_like(out)
+    from diffuvolume_amd import _lib
+    xd, w1d, w2d, dd = dev(x), dev(w1), dev(w2), dev(dil)
+    _lib.check(_lib.load().dv_patch_volume_f32(xd.data_ptr(), w1d.data_ptr(), w2d.data_ptr(), dd.data_ptr(), out2.data_ptr(),
+                                               *shape, _lib.stream_ptr()), "dv_patch_volume_f32")
+    torch.testing.assert_close(out2.cpu(), ref, atol=2e-5, rtol=1e-5)
 
 
 def test_single_channel_head_is_stride1_only():

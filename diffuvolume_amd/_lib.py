@@ -37,6 +37,9 @@ SIGNATURES = {
     "dv_concat_volume_f32": (c_int, [P, P, P, I, I, I, I, I, I, P]),
     "dv_concat_attn_volume_f32": (c_int, [P, P, P, P, I, I, I, I, I, P]),
     "dv_concat_prob_volume_f32": (c_int, [P, P, P, P, I, I, I, I, I, P]),
+    "dv_pointwise_expand_packed_floats": (c_size_t, [I, I]),
+    "dv_pointwise_expand_pack_weights_f32": (c_int, [P, P, I, I, P]),
+    "dv_pointwise_expand_f32": (c_int, [P, P, P, I, I, I, I, P]),
     "dv_softmax_d_f32": (c_int, [P, P, I, I, I, P]),
     "dv_mul_f32": (c_int, [P, P, P, c_size_t, P]),
     "dv_conv3d_rank1_filter_f32": (c_int, [P, P, P, P, P, P, I, I, I, I, I, I, P]),

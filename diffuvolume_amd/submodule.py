@@ -481,6 +481,40 @@ class ReplicaPlanCache:
         self.__dict__.pop("_replica_plans", None)
 
 
+class PointwiseExpandPlan:
+    """A 1x1 Conv2d(bias=False) from few input channels (<= 32) to many output channels, nothing fused: the per-pair
+    table convolutions of ``Rank1FilterPlan`` (csrc/pointwise_expand.hip).  weight [Cout, Cin, 1, 1] or [Cout, Cin]."""
+
+    MAX_CIN = 32
+
+    def __init__(self, weight: torch.Tensor):
+        w = _dev_f32(weight.detach(), "weight")
+        w = w.reshape(w.shape[0], -1).contiguous()
+        self.cout, self.cin = w.shape
+        if self.cin > self.MAX_CIN:
+            raise _lib.DiffuVolumeError(f"PointwiseExpandPlan: at most {self.MAX_CIN} input channels")
+        lib = _lib.load()
+        with torch.cuda.device(w.device):
+            self.wpacked = torch.empty(lib.dv_pointwise_expand_packed_floats(self.cin, self.cout), dtype=torch.float32,
+                                       device=w.device)
+            _lib.check(lib.dv_pointwise_expand_pack_weights_f32(w.data_ptr(), self.wpacked.data_ptr(), self.cin, self.cout,
+                                                                _lib.stream_ptr()), "dv_pointwise_expand_pack_weights_f32")
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        x = _dev_f32(x, "x")
+        b, cin, h, w = x.shape
+        if cin != self.cin:
+            raise RuntimeError(f"expected {self.cin} input channels, got {cin}")
+        out = torch.empty((b, self.cout, h, w), dtype=torch.float32, device=x.device)
+        lib = _lib.load()
+        with torch.cuda.device(x.device):
+            timed(f"pointwise_expand_co{self.cout}", 2.0 * out.numel() * cin, 4.0 * (x.numel() + out.numel()),
+                  lambda: _lib.check(lib.dv_pointwise_expand_f32(x.data_ptr(), self.wpacked.data_ptr(), out.data_ptr(), b, cin,
+                                                                 h * w, self.cout, _lib.stream_ptr()), "dv_pointwise_expand_f32"),
+                  issued=2.0 * out.numel() * 32)
+        return out
+
+
 class Rank1FilterPlan:
     """The first layer of a DiffuVolume step, ``relu(bn(conv3d(volume * noise)))`` (acv_ddim.py:260 + dres0[0],
     :200-203), on the FACTORS of its input instead of the [B,64,48,h,w] volume: with volume = p * [L ; R(x-d)]
@@ -502,8 +536,10 @@ class Rank1FilterPlan:
         # table weights: output channel = tap * Cout + co
         wl = w[:, :self.c].permute(2, 3, 4, 0, 1).reshape(27 * self.cout, self.c, 1, 1).contiguous()
         wr = w[:, self.c:].permute(2, 3, 4, 0, 1).reshape(27 * self.cout, self.c, 1, 1).contiguous()
-        self.table_l = Conv2dPlan(wl, None, act=ACT_NONE)
-        self.table_r = Conv2dPlan(wr, None, act=ACT_NONE)
+        # few input channels -> 27 * Cout output channels, nothing fused: an HBM write stream with its own kernel
+        # (csrc/pointwise_expand.hip; the generic 2-D convolution stays for more than 32 input channels)
+        mk = PointwiseExpandPlan if self.c <= PointwiseExpandPlan.MAX_CIN else (lambda t: Conv2dPlan(t, None, act=ACT_NONE))
+        self.table_l, self.table_r = mk(wl), mk(wr)
         self.scale, self.shift = _fold_bn(bn, None, self.cout, w.device, eps)
 
     def applies(self, volume) -> bool:

@@ -71,6 +71,13 @@ int dv_concat_prob_volume_f32(const float* ref, const float* tgt, const float* p
  * dv_mul_f32: out = x * y elementwise (s = p * n01).
  * dv_conv3d_rank1_filter_f32: s [B,D,H,W], gl / gr [B,27*Cout,H,W] (channel = tap*Cout + co, tap = (kd*3+ky)*3+kx)
  *   -> out [B,Cout,D,H,W] = act(scale * conv + bias); D <= 48. */
+/* The tables themselves: a 1x1 convolution from few input channels (Cin <= 32: the concat features) to many output
+ * channels (27 * Cout of the layer), no BatchNorm / activation: in [B,Cin,HW] -> out [B,Cout,HW] = W [Cout,Cin] . in.
+ * A pure HBM write stream (csrc/pointwise_expand.hip).  Weights are packed once (dv_pointwise_expand_packed_floats floats). */
+size_t dv_pointwise_expand_packed_floats(int Cin, int Cout);
+int dv_pointwise_expand_pack_weights_f32(const float* w, float* wpacked, int Cin, int Cout, dv_stream_t stream);
+int dv_pointwise_expand_f32(const float* in, const float* wpacked, float* out, int B, int Cin, int HW, int Cout,
+                            dv_stream_t stream);
 int dv_softmax_d_f32(const float* att, float* p, int B, int D, int HW, dv_stream_t stream);
 int dv_mul_f32(const float* x, const float* y, float* out, size_t n, dv_stream_t stream);
 int dv_conv3d_rank1_filter_f32(const float* s, const float* gl, const float* gr, const float* ch_scale,

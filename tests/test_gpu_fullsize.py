@@ -148,15 +148,23 @@ def _f64_state_dict(sd):
     return {k: (v.double() if v.is_floating_point() and not k.startswith("time_embedding") else v) for k, v in sd.items()}
 
 
-def oracle_run(pair, gain):
+def oracle_run(pair, gain, calibrated=False):
     """The CPU oracle's 5-step run of one pair of the bench workload (960x512), cached for the tests of this module:
-    weights `synth_state_dict(seed=1, logit_gain=gain)`, inputs `synth_hot_inputs(seed=100)`, NoiseTape(1)."""
-    key = (pair, gain)
+    weights `synth_state_dict(seed=1, logit_gain=gain)`, inputs `synth_hot_inputs(seed=100)`, NoiseTape(1).
+    ``calibrated``: the BatchNorm buffers of the loop layers come from tests/golden/acv_calibrated_fullsize.npz
+    (oracle/calibrate.py: the statistics of this very input, as a trained checkpoint's buffers would hold them)."""
+    key = (pair, gain, calibrated)
     if key not in _ORACLE_RUNS:
         from diffuvolume_amd.synth import synth_hot_inputs
         from oracle import acv_oracle as O
         from oracle import loop_parity as LP
         sd = synth_state_dict(dv.ACVNet_DDIM(192, False, False).state_dict(), seed=1, logit_gain=gain)
+        if calibrated:
+            from conftest import load_golden
+            from oracle import calibrate as C
+            g = load_golden("acv_calibrated_fullsize")
+            assert float(g["gain"]) == gain
+            sd.update(C.unpack(g["bn_keys"], g["bn_vals"], g["bn_lens"]))
         model = dv.ACVNet_DDIM(192, False, False)
         model.load_state_dict(sd, strict=True)
         model = model.to(DEV).eval()
@@ -240,6 +248,31 @@ def test_fullsize_fp64_triangulation():
         assert h["frac_gt_1e-3"] <= LP.BAR_FRAC, ("HIP vs float64, raw bar, all pixels", s)
         assert h["mean_abs_px"] <= 1.5 * o["mean_abs_px"] + 2e-5, s
         assert h["frac_gt_1e-3"] <= 2.0 * o["frac_gt_1e-3"] + 2e-4, s
+
+
+def test_fullsize_oracle_5step_calibrated():
+    """The contract as written, on ALL pixels, at the BASELINE size.  Network: the synthetic ACVNet_DDIM weights with
+    the BatchNorm buffers of the loop layers holding the statistics of the data (oracle/calibrate.py,
+    oracle/make_golden_acv_calibrated.py) and classifier gain 1 -- every layer's output is O(1), the logits stay within
+    +-25, and the fp32 oracle is within 1e-3 px of its own float64 evaluation on EVERY pixel at every step (measured on
+    the CPU: max 9.8e-4 px).  On such a network two fp32 evaluations can be held to the raw bars: per teacher-forced
+    step |d disp| <= 1e-3 px on 99.9 % of all 491 520 pixels and |d EPE| < 1e-4, the same for HIP's own trajectory
+    under the oracle's decisions, for the free run when no renewal decision differs, and for the final output."""
+    from oracle import loop_parity as LP
+    r = oracle_run(0, 1.0, calibrated=True)
+    model, x, trace = r["model"], r["x"], r["trace"]
+    tf = LP.teacher_forced(model, trace, r["vol_d"], r["used_d"], x["used"], x["gt"])
+    df = LP.decision_forced(model, trace, r["vol_d"], r["used_d"], r["x_T"], x["gt"])
+    fr = LP.free_run(model, trace, r["stack_o"], r["final_o"], r["vol_d"], r["used_d"], r["x_T"], x["gt"], seed=1)
+    _dump("parity_fullsize_5step_calibrated", {"network": "BatchNorm buffers = data statistics, classifier gain 1",
+                                               "teacher_forced": tf, "decision_forced": df, "free_run": fr})
+    for s in tf:
+        assert s["frac_gt_1e-3"] <= LP.BAR_FRAC and s["epe_delta"] < LP.BAR_EPE, ("teacher forced, raw bars, all pixels", s)
+    flips = sum(s["flips_mask_zero"] for s in fr["steps"])
+    for s in df + (fr["steps"] if flips == 0 else []):
+        assert s["frac_gt_1e-3"] <= LP.BAR_FRAC and s["epe_delta"] < LP.BAR_EPE, s
+    assert fr["final"]["epe_delta"] < LP.BAR_EPE, fr["final"]
+    assert fr["final"]["frac_gt_1e-3"] <= LP.BAR_FRAC or flips > 0, fr["final"]
 
 
 def test_fullsize_oracle_5step_conditioned():

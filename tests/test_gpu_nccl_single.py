@@ -48,5 +48,5 @@ def test_bench_under_a_launcher_environment_uses_rccl_at_one_rank():
                         "--no-cpu-baseline", "--no-extras"], env=_env(), capture_output=True, text=True, timeout=800, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _json_line(r.stdout)
-    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["dist_backend"] == "nccl" and d["launcher"] == "torchrun"
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["dist_backend"] == "nccl" and d["launcher"] == "env"      # a launcher ENVIRONMENT (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_PORT), no torchrun process
     assert d["value"] > 0 and d["config"]["global_batch"] == 2

@@ -149,6 +149,21 @@ def test_ddim_sample_on_a_mutated_volume_matches_the_oracle(acv_state_dict):
     assert t1[0]["mean_abs_px"] > 10 * tf[0]["mean_abs_px"]             # (the unmasked loop is a different function)
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 864, 16, 60), (1, 8, 162, 5, 7), (3, 30, 27, 3, 21), (1, 32, 864, 128, 240)])
+def test_table_convolution_vs_torch(shape):
+    """The per-pair table build (csrc/pointwise_expand.hip): a 1x1 convolution from <= 32 input channels to 27 * Cout
+    output channels against F.conv2d -- pixel counts that are not multiples of 4 / 64, channel counts that are not
+    multiples of 4 / 16, the bench size."""
+    b, cin, cout, h, w = shape
+    g = _gen(221, str(shape))
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) * cin ** -0.5
+    ref = F.conv2d(x[:1].double(), wt.double()).float() if h * w > 10000 else F.conv2d(x, wt)
+    out = S.PointwiseExpandPlan(wt.to(DEV))(x.to(DEV))
+    assert out.shape == (b, cout, h, w)
+    assert rel(out[:ref.shape[0]], ref) < 2e-6, rel(out[:ref.shape[0]], ref)
+
+
 def test_model_takes_the_factored_layer_and_agrees_with_the_generic_one(acv_state_dict):
     """ACVNet_DDIM.model_predictions on a volume that carries its factors vs the same volume stripped of them: the two
     first-layer paths give the same step (cost within 1e-5 of its scale, disparity within the contract)."""

@@ -30,7 +30,7 @@ for f in glob.glob(str(src / "p*" / "**" / "*counter_collection.csv"), recursive
 out = []
 for k, cs in agg.items():
     if not any(s in k for s in ("conv", "gwc_rows", "concat_rows", "window_attn", "upsample_softmax", "ddim_step",
-                                "geo_", "corr", "refine_inputs")):
+                                "geo_", "corr", "refine_inputs", "rank1", "pw_expand", "patch_volume")):
         continue
     c = {n: sum(v) / len(v) for n, v in cs.items()}
     rec = {"kernel": k, "launches": max(len(v) for v in cs.values()), "counters_per_launch": {n: round(v, 1) for n, v in sorted(c.items())}}

@@ -730,30 +730,36 @@ class IGEVStereo_ddim(nn.Module):
                        "dv_encode_two_hot_f32")
         return x
 
+    def _front(self, image1, image2):
+        """:364-400 up to the GRU inputs: feature pyramid + stems, matching features, cost volume + initial disparity,
+        context encoder, geometry lookup object.  Shared with the origin network (igev_stereo.py:151-194)."""
+        image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
+        image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
+        features_left, features_right = self.feature(image1), self.feature(image2)
+        stem_2x = self.stem_2(image1)
+        stem_4x = self.stem_4(stem_2x)
+        stem_4y = self.stem_4(self.stem_2(image2))
+        features_left[0] = torch.cat((features_left[0], stem_4x), 1)
+        features_right[0] = torch.cat((features_right[0], stem_4y), 1)
+        match_left = self.desc(self.conv(features_left[0])).float().contiguous()
+        match_right = self.desc(self.conv(features_right[0])).float().contiguous()
+        geo, init_disp = self.cost_volume(match_left, match_right, features_left)
+        cnet_list = self.cnet(image1, num_layers=self.args.n_gru_layers)
+        net_list = [torch.tanh(x[0]) for x in cnet_list]
+        inp_list = [torch.relu(x[1]) for x in cnet_list]
+        inp_list = [list(conv(i).split(split_size=conv.out_channels // 3, dim=1))
+                    for i, conv in zip(inp_list, self.context_zqr_convs)]
+        inp_list = [[t.contiguous() for t in trio] for trio in inp_list]
+        from .geometry_ddim import Combined_Geo_Encoding_Volume
+        geo_fn = Combined_Geo_Encoding_Volume(match_left, match_right, geo, radius=self.args.corr_radius,
+                                              num_levels=self.args.corr_levels)
+        return features_left, stem_2x, init_disp, net_list, inp_list, geo_fn
+
     def forward(self, image1, image2, flow_full, flow_gt, iters=12, flow_init=None, test_mode=False, noise=None):
         if self.training:
             raise NotImplementedError("the MI355X DiffuVolume path is inference-only (model.eval())")
         with torch.no_grad():
-            image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
-            image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
-            features_left, features_right = self.feature(image1), self.feature(image2)
-            stem_2x = self.stem_2(image1)
-            stem_4x = self.stem_4(stem_2x)
-            stem_4y = self.stem_4(self.stem_2(image2))
-            features_left[0] = torch.cat((features_left[0], stem_4x), 1)
-            features_right[0] = torch.cat((features_right[0], stem_4y), 1)
-            match_left = self.desc(self.conv(features_left[0])).float().contiguous()
-            match_right = self.desc(self.conv(features_right[0])).float().contiguous()
-            geo, init_disp = self.cost_volume(match_left, match_right, features_left)
-            cnet_list = self.cnet(image1, num_layers=self.args.n_gru_layers)
-            net_list = [torch.tanh(x[0]) for x in cnet_list]
-            inp_list = [torch.relu(x[1]) for x in cnet_list]
-            inp_list = [list(conv(i).split(split_size=conv.out_channels // 3, dim=1))
-                        for i, conv in zip(inp_list, self.context_zqr_convs)]
-            inp_list = [[t.contiguous() for t in trio] for trio in inp_list]
-            from .geometry_ddim import Combined_Geo_Encoding_Volume
-            geo_fn = Combined_Geo_Encoding_Volume(match_left, match_right, geo, radius=self.args.corr_radius,
-                                                  num_levels=self.args.corr_levels)
+            _, stem_2x, init_disp, net_list, inp_list, geo_fn = self._front(image1, image2)
             x0 = self.encode_disparity(flow_gt)
             pred = self.ddim_sample(init_disp, init_disp, flow_init, iters, net_list, inp_list, geo_fn, flow_full, x0,
                                     stem_2x, noise=noise)

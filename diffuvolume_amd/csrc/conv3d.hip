@@ -171,9 +171,6 @@ __global__ __launch_bounds__(256, G::WPS) void conv3d_mfma_kernel(ConvArgs a) {
     }
   };
   auto commit = [&](int c0) {  // registers -> LDS
-#ifdef DV_COMMIT_PRIO
-    asm volatile("s_setprio %0" ::"n"(DV_COMMIT_PRIO) : "memory");
-#endif
 #pragma unroll
     for (int cl = 0; cl < G::KC; ++cl) {
 #pragma unroll
@@ -187,9 +184,6 @@ __global__ __launch_bounds__(256, G::WPS) void conv3d_mfma_kernel(ConvArgs a) {
       const int e = tid + 256 * q;
       if (e < NQ) reinterpret_cast<f32x4*>(w_s)[e] = vw[q];
     }
-#ifdef DV_COMMIT_PRIO
-    asm volatile("s_setprio 0" ::: "memory");
-#endif
   };
 
   fetch(0);

@@ -231,15 +231,9 @@ __global__ __launch_bounds__(256, MTW == 1 ? 2 : 1) void conv3d_wino_kernel(Wino
   char* const smem_b = reinterpret_cast<char*>(smem);
 
   auto commit_next_cl = [&](int cl) __attribute__((always_inline)) {   // into the other buffer, running offsets
-#ifdef DV_COMMIT_PRIO
-    asm volatile("s_setprio %0" ::"n"(DV_COMMIT_PRIO) : "memory");
-#endif
 #pragma unroll
     for (int i = 0; i < NS; ++i)
       *reinterpret_cast<float*>(smem_b + wo[i] + 4 * cl * RAWP) = HAS_SCALE ? vin[cl][i] * scl[i] : vin[cl][i];
-#ifdef DV_COMMIT_PRIO
-    asm volatile("s_setprio 0" ::: "memory");
-#endif
   };
 
   fetch_raw(0);

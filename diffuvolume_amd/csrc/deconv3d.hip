@@ -152,9 +152,6 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
     }
   };
   auto commit = [&](int c) {
-#ifdef DV_COMMIT_PRIO
-    asm volatile("s_setprio %0" ::"n"(DV_COMMIT_PRIO) : "memory");
-#endif
 #pragma unroll
     for (int cl = 0; cl < kKC; ++cl)
 #pragma unroll
@@ -164,9 +161,6 @@ __global__ __launch_bounds__(256, 2) void deconv3d_mfma_kernel(DeconvArgs a) {
       const int e = tid + 256 * q;
       if (e < NQ) reinterpret_cast<f32x4*>(w_s)[e] = vw[q];
     }
-#ifdef DV_COMMIT_PRIO
-    asm volatile("s_setprio 0" ::: "memory");
-#endif
   };
 
   // input offsets a tap can ask for per dimension: K=3 -> {0,+1}, K=4 -> {-1,0,+1}

@@ -36,7 +36,8 @@ fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
 kernels = []
 for k in sorted(fetch, key=lambda k: -sum(fetch[k])):
     if not any(s in k for s in ("conv3d", "deconv3d", "gwc_rows", "concat_rows", "window_attn", "upsample_softmax",
-                                "ddim_step", "noise_prepare", "encode_two_hot", "masked_metrics")):
+                                "ddim_step", "noise_prepare", "encode_two_hot", "masked_metrics", "rank1", "pw_expand", "patch_volume",
+                                "softmax_d", "mul2")):
         continue
     f_kb = sum(fetch[k]) / len(fetch[k])
     w_kb = sum(write[k]) / len(write[k]) if write.get(k) else 0.0

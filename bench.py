@@ -299,6 +299,34 @@ def parity_vs_oracle(model, x, ref):
             "final_within_raw_bars": fr["final"]["frac_gt_1e-3"] <= LP.BAR_FRAC and fr["final"]["epe_delta"] < LP.BAR_EPE}
 
 
+def parity_calibrated(a, host, x, device):
+    """The same comparison on the CALIBRATED network (oracle/calibrate.py): these synthetic weights with the BatchNorm
+    buffers of the loop layers holding the statistics of the data (tests/golden/acv_calibrated_fullsize.npz, written by
+    oracle/make_golden_acv_calibrated.py; classifier gain 1), as a trained checkpoint's buffers would.  On it the fp32
+    oracle is within 1e-3 px of its own float64 evaluation on every pixel, so `within_raw_bars` -- the contract as
+    written, all pixels, every step -- is a statement about the implementation and not about the conditioning of an
+    untrained network.  Not timed; the oracle is the checker."""
+    import numpy as np
+    import diffuvolume_amd as dv
+    from diffuvolume_amd.synth import synth_state_dict
+    from oracle import calibrate as C
+    f = ROOT / "tests" / "golden" / "acv_calibrated_fullsize.npz"
+    if not f.exists():
+        return {"error": "tests/golden/acv_calibrated_fullsize.npz is missing"}
+    with np.load(f, allow_pickle=False) as z:
+        gain, stats = float(z["gain"]), C.unpack(z["bn_keys"], z["bn_vals"], z["bn_lens"])
+    m = dv.ACVNet_DDIM(192, False, False)
+    sd = synth_state_dict(m.state_dict(), seed=1, logit_gain=gain)
+    sd.update(stats)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(device).eval()
+    _, ref = cpu_baseline(sd, host, a.ddim_steps, m.ensemble_cof)
+    rep = parity_vs_oracle(m, x, ref)
+    rep["network"] = ("BatchNorm buffers of dres0..classif2 = statistics of the synthetic data, classifier gain "
+                      f"{gain:g} (logits within +-25; the default bench network: random buffers, gain 8)")
+    return rep
+
+
 def extras(a, sd, x, mask, device):
     """Side measurements (not `value`): (1) the timed step replayed from a hipGraph; (2) the end-to-end `test_sample`
     equivalent of SceneFlow/test_sceneflow_ddim.py:89-122 -- origin ACVNet -> used/disp -> ACVNet_DDIM.forward ->
@@ -582,6 +610,8 @@ def main():
         out["cpu_baseline"] = base
         out["parity_vs_oracle"] = parity_vs_oracle(model, x, ref)
         del ref
+        if a.ddim_steps == 5:
+            out["parity_vs_oracle_calibrated"] = parity_calibrated(a, host, x, device)
     if rank == 0 and world == 1 and not a.no_extras:
         out["extras"] = extras(a, sd, x, mask, device)
     if torch.distributed.is_initialized():

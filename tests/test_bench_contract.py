@@ -50,3 +50,18 @@ def test_cpu_baseline_and_parity_leg():
     assert len(p["teacher_forced"]) == d["config"]["ddim_steps"]
     assert all(s["epe_delta"] < p["bars"]["epe"] for s in p["teacher_forced"] + p["free_run"])
     assert p["free_run_final"]["epe_delta"] < p["bars"]["epe"]
+
+
+def test_calibrated_network_meets_the_raw_bars_on_all_pixels():
+    """Round 4 on: the bench line carries a second parity leg on the calibrated network (BatchNorm buffers = statistics
+    of the data), where the contract holds as written -- every step, all pixels (a tight ceiling, not a
+    multiple of the contract)."""
+    d = latest()
+    p = d.get("parity_vs_oracle_calibrated")
+    if p is None:                       # a bench line of an earlier round
+        return
+    assert "error" not in p, p
+    assert p["within_raw_bars"] is True and p["final_within_raw_bars"] is True
+    assert all(s["frac_gt_1e-3"] <= p["bars"]["frac"] and s["epe_delta"] < p["bars"]["epe"] for s in p["teacher_forced"])
+    if sum(s["flips_mask_zero"] for s in p["free_run"]) == 0:
+        assert all(s["frac_gt_1e-3"] <= p["bars"]["frac"] for s in p["free_run"])

@@ -49,3 +49,34 @@ def test_sample(model_origin, model, sample: Dict, maxdisp: int = 192, device: s
     disp_ests = model(img_l, img_r, disp_, disp_net, None)
     out = M.batch_metrics(disp_ests[0], disp_gt, mask_gt)
     return {k: float(v) for k, v in out.items()}
+
+
+def _sintel_pad(ht: int, wd: int, divis_by: int = 32):
+    """core/utils/utils.py:9-14 (`InputPadder`, mode 'sintel'): (left, right, top, bottom) replicate padding."""
+    pad_ht = (((ht // divis_by) + 1) * divis_by - ht) % divis_by
+    pad_wd = (((wd // divis_by) + 1) * divis_by - wd) % divis_by
+    return [pad_wd // 2, pad_wd - pad_wd // 2, pad_ht // 2, pad_ht - pad_ht // 2]
+
+
+@torch.no_grad()
+def validate_kitti_sample(model_origin, model, image1: torch.Tensor, image2: torch.Tensor, flow_gt: torch.Tensor,
+                          valid_gt: torch.Tensor, iters: int = 32, device: str = "cuda") -> Dict[str, float]:
+    """One item of KITTI15/evaluate_stereo.py:80-117 (`validate_kitti`): pad to a multiple of 32, origin IGEV-Stereo ->
+    `flow_pr`, its clamped quarter-resolution copy `flow_4`, `IGEVStereo_ddim` -> refined disparity, unpad, per-image EPE
+    and D1 (> 3 px) over the valid pixels.  image1 / image2 [3,H,W] in 0..255, flow_gt [1,H,W], valid_gt [H,W]."""
+    model.eval()
+    model_origin.eval()
+    image1, image2 = image1[None].to(device), image2[None].to(device)
+    pad = _sintel_pad(*image1.shape[-2:])
+    image1, image2 = (F.pad(x, pad, mode="replicate") for x in (image1, image2))
+    flow_pr = model_origin(image1, image2, iters=iters, test_mode=True)
+    b, c, h, w = image1.shape
+    flow_ori = torch.clamp(flow_pr, 0, w - 1)
+    flow_4 = F.interpolate(flow_ori, size=(h // 4, w // 4), mode="bilinear") / 4
+    _, flow_refine = model(image1, image2, flow_pr, flow_4, iters=iters, test_mode=True)
+    flow_refine = flow_refine.reshape(b, 1, h, w)
+    flow_refine = flow_refine[..., pad[2]:h - pad[3], pad[0]:w - pad[1]].cpu().squeeze(0)
+    assert flow_refine.shape == flow_gt.shape, (flow_refine.shape, flow_gt.shape)
+    epe = torch.sum((flow_refine - flow_gt.cpu()) ** 2, dim=0).sqrt().flatten()
+    val = (valid_gt.cpu().flatten() >= 0.5) & (flow_gt.cpu().abs().flatten() < 192)
+    return {"epe": float(epe[val].mean()), "d1": float((epe > 3.0)[val].float().mean())}

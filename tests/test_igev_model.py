@@ -259,3 +259,23 @@ def test_origin_forward_vs_the_reference_class():
     # on the second call, so the two results agree to fp32 re-association, not necessarily bit for bit
     dd = (preds[-1] - pred).abs()
     assert float(dd.mean()) < 5e-4 and float(dd.max()) < 2e-2, (float(dd.mean()), float(dd.max()))
+
+
+@pytest.mark.gpu
+def test_validate_kitti_sample_runs_the_two_networks_back_to_back():
+    """KITTI15/evaluate_stereo.py:80-117 on one synthetic item of a size that needs padding (370 x 1226 -> 384 x 1248):
+    origin network -> flow_pr / flow_4 -> DiffuVolume network -> unpadded disparity -> EPE / D1."""
+    from diffuvolume_amd.pipeline import _sintel_pad, validate_kitti_sample
+    assert _sintel_pad(370, 1226) == [11, 11, 7, 7] and _sintel_pad(384, 1248) == [0, 0, 0, 0]
+    scale = {"update_block.disp_head.conv2.weight": 0.05, "update_block.disp_head.conv2.bias": 0.0, "classifier.weight": 20.0}
+    origin, ddim = build_origin(), build()
+    origin.load_state_dict(synth_state_dict(origin.state_dict(), seed=8, scale=scale), strict=True)
+    ddim.load_state_dict(synth_state_dict(ddim.state_dict(), seed=7, scale=scale), strict=True)
+    origin, ddim = origin.to(DEV).eval(), ddim.to(DEV).eval()
+    g = _gen(78, "kitti")
+    img1 = torch.rand(3, 370, 1226, generator=g) * 255
+    img2 = torch.roll(img1, -9, dims=-1)
+    gt = (36 + torch.randn(1, 370, 1226, generator=g)).clamp(1, 190)
+    valid = (torch.rand(370, 1226, generator=g) > 0.3).float()
+    out = validate_kitti_sample(origin, ddim, img1, img2, gt, valid, iters=4)
+    assert set(out) == {"epe", "d1"} and 0.0 <= out["d1"] <= 1.0 and out["epe"] >= 0.0 and out["epe"] == out["epe"]

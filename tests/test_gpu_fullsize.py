@@ -213,7 +213,9 @@ def test_fullsize_oracle_5step(pair):
     for s in tf:
         assert s["epe_delta"] < LP.BAR_EPE, ("teacher forced", s)
         assert s["frac_gt_1e-3_where_unc_lt_3"] <= LP.BAR_FRAC, ("teacher forced, confident pixels, raw bar", s)
-        assert s["frac_gt_1e-3"] <= 2e-3, ("teacher forced, all pixels, raw ceiling", s)
+        # (default network: a recorded diagnostic with a ceiling just above the measured 0.03-0.13 %; the contract's own
+        # all-pixel bar is asserted on the calibrated network, test_fullsize_oracle_5step_calibrated)
+        assert s["frac_gt_1e-3"] <= 1.6e-3, ("teacher forced, all pixels, raw ceiling", s)
         assert s["frac_gt_bar"] <= LP.BAR_FRAC, ("teacher forced", s)
         assert s["mask_max_abs"] <= 1.0
         if "x_next_max_abs_where_decisions_agree" in s:
@@ -223,7 +225,7 @@ def test_fullsize_oracle_5step(pair):
         # trajectory level (HIP on its own state): the contract's EPE bar at every step, the raw pixel bar on the
         # confident pixels -- at this size the step map does not amplify the 1e-4 px state differences beyond it
         assert s["epe_delta"] < LP.BAR_EPE, s
-        assert s["frac_gt_1e-3_where_unc_lt_3"] <= LP.BAR_FRAC and s["frac_gt_1e-3"] <= 3e-3, s
+        assert s["frac_gt_1e-3_where_unc_lt_3"] <= LP.BAR_FRAC and s["frac_gt_1e-3"] <= 2e-3, s
     assert fr["final"]["epe_delta"] < LP.BAR_EPE, fr["final"]
     assert fr["final"]["frac_gt_1e-3"] <= LP.BAR_FRAC or flips > 0, fr["final"]   # the ensemble output: raw contract bar
 

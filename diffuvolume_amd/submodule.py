@@ -204,6 +204,9 @@ class AttentionConcatVolume:
         if self._tensor is None:
             b, c2, d, h, w = self.shape
             out = torch.empty(tuple(self.shape), dtype=torch.float32, device=self.device)
+            if out.numel() == 0:
+                self._tensor = out
+                return out
             lib = _lib.load()
             with torch.cuda.device(self.device):
                 timed("concat_attn_volume", 2.0 * out.numel(),
@@ -224,6 +227,8 @@ def _attention_factors(refimg_fea, targetimg_fea, att_weights, maxdisp):
     if ref.shape != tgt.shape or tuple(att.shape) != (b, 1, maxdisp, h, w):
         raise RuntimeError("shape mismatch between features and attention weights")
     p_att = torch.empty((b, maxdisp, h, w), dtype=torch.float32, device=ref.device)
+    if p_att.numel() == 0:              # empty batch / image: the reference's product is the empty volume
+        return ref, tgt, att, p_att
     with torch.cuda.device(ref.device):
         _lib.check(_lib.load().dv_softmax_d_f32(att.data_ptr(), p_att.data_ptr(), b, maxdisp, h * w, _lib.stream_ptr()),
                    "dv_softmax_d_f32")
@@ -248,6 +253,8 @@ def build_concat_attention_volume(refimg_fea: torch.Tensor, targetimg_fea: torch
     if lazy:
         return handle
     out = torch.empty((b, 2 * c, maxdisp, h, w), dtype=torch.float32, device=ref.device)
+    if out.numel() == 0:
+        return out
     lib = _lib.load()
     with torch.cuda.device(ref.device):
         timed("concat_attn_volume", 2.0 * out.numel(), 4.0 * (2 * ref.numel() + att.numel() + out.numel()),

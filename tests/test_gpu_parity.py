@@ -739,6 +739,10 @@ def test_builder_edge_shapes():
     assert tuple(e.shape) == (0, 4, 3, 2, 4)
     assert tuple(S.build_concat_volume(torch.zeros(0, 8, 2, 4, device=DEV), torch.zeros(0, 8, 2, 4, device=DEV), 3).shape) == (0, 16, 3, 2, 4)
     assert tuple(S.disparity_regression(torch.zeros(0, 5, 2, 4, device=DEV), 5).shape) == (0, 2, 4)
+    z = lambda *sh: torch.zeros(*sh, device=DEV)
+    assert tuple(S.build_concat_attention_volume(z(0, 8, 2, 4), z(0, 8, 2, 4), z(0, 1, 3, 2, 4), 3).shape) == (0, 16, 3, 2, 4)
+    lazy = S.build_concat_attention_volume(z(0, 8, 2, 4), z(0, 8, 2, 4), z(0, 1, 3, 2, 4), 3, lazy=True)
+    assert tuple(lazy.shape) == (0, 16, 3, 2, 4) and tuple(lazy.tensor().shape) == (0, 16, 3, 2, 4)
     g = _gen(141, "edge")
     for shape, d, groups in (((1, 8, 1, 1), 4, 2), ((2, 16, 3, 5), 12, 4)):      # W < maxdisp: mostly zero wedge
         l, r = torch.randn(*shape, generator=g), torch.randn(*shape, generator=g)

@@ -186,3 +186,28 @@ def test_model_takes_the_factored_layer_and_agrees_with_the_generic_one(acv_stat
     dd = (d1 - d2).abs()
     assert float((dd > 1e-3).float().mean()) <= 1e-3 and float(dd.mean()) < 1e-4, (float(dd.mean()), float(dd.max()))
     assert AD.RANK1_FILTER is True
+
+
+def test_factor_handle_without_the_rank1_layer_is_materialised(acv_state_dict):
+    """With the rank-1 layer switched off (the split-fp16 precision does that too) the factor handle is materialised once
+    and the generic first layer runs on the tensor: same result as handing over the tensor."""
+    from diffuvolume_amd import acv_ddim as AD
+    g = _gen(231, "off")
+    b, h, w = 1, 8, 20
+    L, R = torch.randn(b, 32, h, w, generator=g).to(DEV), torch.randn(b, 32, h, w, generator=g).to(DEV)
+    att = (torch.randn(b, 1, 48, h, w, generator=g) * 2).to(DEV)
+    x_t = torch.randn(b, 48, h, w, generator=g).to(DEV)
+    t = torch.full((b,), 999, dtype=torch.long, device=DEV)
+    AD.RANK1_FILTER = False
+    try:
+        m = dv.ACVNet_DDIM(192, False, False)
+        m.load_state_dict(acv_state_dict, strict=True)
+        m = m.to(DEV).eval()
+        assert m.prepare().dres0_rank1 is None
+        handle = dv.build_concat_attention_volume(L, R, att, 48, lazy=True)
+        d_handle = m.model_predictions(handle, x_t, t)[2]
+        assert handle._tensor is not None
+        d_tensor = m.model_predictions(dv.build_concat_attention_volume(L, R, att, 48), x_t, t)[2]
+        assert torch.equal(d_handle, d_tensor)
+    finally:
+        AD.RANK1_FILTER = True

@@ -795,6 +795,15 @@ extern "C" int dv_conv3d_f32(const float* in, const float* wpacked, const float*
   if (k == 3 && stride == 2) {
     if (a.Coutp == 16) return launch_conv<Geo<3, 2, 1, 2, 4, 2, 4, 2>>(a, s);
     if (a.Coutp == 32) return launch_conv<Geo<3, 2, 2, 2, 4, 2, 4, 2>>(a, s);
+    // Launches that are small PER BATCH ITEM (the 64 -> 128 layers of the hourglasses: 192 blocks per pair) run 4 % faster
+    // on 2 x 2 x 32 tiles at three blocks per CU (53.6 KB of LDS, 135 VGPRs): 0.730 -> 0.700 ms at batch 8; the 32 -> 64
+    // layers (768 blocks per pair) are unchanged by it (profiles/r04_kernel_experiments.txt).  The choice looks at one
+    // batch item only and both tilings sum every output in the same order (chunk by chunk, tap by tap), so a shard of a
+    // batch reproduces the batch's bits.  DV_S2_TILE=big|small pins it (tests).
+    const char* pin = getenv("DV_S2_TILE");          // (read per launch: the tests flip it inside one process)
+    const long long per_item = (long long)(a.Coutp / 64) * ((a.Do + 1) / 2) * ((a.Ho + 3) / 4) * ((a.Wo + 31) / 32);
+    const bool small = pin ? pin[0] == 's' : per_item < 512;
+    if (small) return launch_conv<Geo<3, 2, 4, 2, 2, 2, 4, 3>>(a, s);
     return launch_conv<Geo<3, 2, 4, 2, 4, 2, 4, 2>>(a, s);
   }
   // k == 1

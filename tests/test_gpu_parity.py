@@ -1036,3 +1036,31 @@ print("OK", h.hexdigest())
         assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
         digests.append(r.stdout.split("OK")[-1].strip())
     assert digests[0] == digests[1] == digests[2], digests
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 128, 8, 12, 60), (1, 32, 64, 6, 9, 37), (1, 16, 64, 4, 8, 64)])
+def test_stride2_tilings_give_the_same_bits(shape):
+    """The stride-2 convolution picks 2 x 4 x 32 or 2 x 2 x 32 output tiles from the size of ONE batch item (csrc/conv3d.hip);
+    both sum every output chunk by chunk, tap by tap, so the choice may not change a bit -- what lets a shard of a batch
+    reproduce the batch (section 6 of DESIGN.md).  Also against F.conv3d."""
+    import os
+    b, cin, cout, d, h, w = shape
+    g = _gen(191, str(shape))
+    x = torch.randn(b, cin, d, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5
+    plan = S.Conv3dPlan(dev(wt), None, stride=2, act=S.ACT_RELU)
+    outs = {}
+    old = os.environ.get("DV_S2_TILE")
+    try:
+        for tile in ("big", "small"):
+            os.environ["DV_S2_TILE"] = tile
+            outs[tile] = plan(dev(x)).clone()
+    finally:
+        if old is None:
+            os.environ.pop("DV_S2_TILE", None)
+        else:
+            os.environ["DV_S2_TILE"] = old
+    assert torch.equal(outs["big"], outs["small"])
+    ref = torch.relu(torch.nn.functional.conv3d(x.double(), wt.double(), None, 2, 1)).float()
+    assert rel_err(outs["small"], ref) < 1e-5
+    assert torch.equal(plan(dev(x)), outs["big"])              # and whichever the launcher picks by itself

@@ -708,8 +708,11 @@ int launch_conv(ConvArgs a, hipStream_t s) {
   a.nco = a.Coutp / G::COUT;
   const long long blocks = (long long)a.B * a.nco * a.ntz * a.nty * a.ntx;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return DV_ERR_SHAPE;
-  // the `volume * noise` prologue is specialised away for the hot Cout=32 layers that never use it
-  constexpr bool kSpecialise = (G::KS == 3 && G::S == 1 && G::NT == 2);
+  // the `volume * noise` prologue is specialised away for the layers that never use it: the hot Cout=32 layers, and
+  // (round 4) the stride-2 layers -- with the prologue compiled in, a launch without a filter still multiplied every
+  // staged value by 1 (48 vector multiplies per thread and chunk on the pipe the MFMAs issue on): 32->64 1.582 -> 1.536 ms,
+  // 64->128 0.701 -> 0.668 ms (profiles/r04_kernel_experiments.txt)
+  constexpr bool kSpecialise = (G::KS == 3 && ((G::S == 1 && G::NT == 2) || G::S == 2));
   if constexpr (kSpecialise) {
     if (!a.in_scale) {
       hipLaunchKernelGGL((conv3d_mfma_kernel<G, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);

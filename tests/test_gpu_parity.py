@@ -170,8 +170,9 @@ def test_conv_oracle(cfg, precision):
                                            bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5)
     plan = S.Conv3dPlan(dev(w), tuple(dev(t) for t in bn), stride=s, act=S.ACT_NONE, precision=precision)
     assert rel_err(plan(dev(x)), y_ref) < 1e-5
-    # fused prologue scale, residual and ReLU (acv_ddim.py:260-262)
-    if s == 1:
+    # fused prologue scale, residual and ReLU (acv_ddim.py:260-262); stride 2 too: it has its own instantiation with the
+    # prologue since round 4 (the one without it is what the networks launch)
+    if s == 1 or k == 3:
         scale = torch.rand(dims[0], *dims[1:], generator=g)
         res = torch.randn(y_ref.shape, generator=g)
         y2 = torch.nn.functional.batch_norm(torch.nn.functional.conv3d(x * scale.unsqueeze(1), w, None, s, (k - 1) // 2),

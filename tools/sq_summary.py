@@ -5,6 +5,7 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 import subprocess
 import sys
@@ -62,8 +63,8 @@ if head is None:
         head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
     except OSError:
         head = None
-doc = {"command": "rocprofv3 --kernel-trace --pmc <8 counters> (two passes) -- python bench.py --steps 1 --warmup 1 "
-                  "--no-cpu-baseline --no-extras --no-kernel-timer", "git_head": head, "csrc_sha16": csrc_sha16(),
+prog = os.environ.get("DV_SQ_ARGS") or "bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --no-kernel-timer"
+doc = {"command": "rocprofv3 --kernel-trace --pmc <8 counters> (two passes) -- python " + prog, "git_head": head, "csrc_sha16": csrc_sha16(),
        "notes": "per-launch averages; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs); "
                 "SQ_INSTS_VALU counts MFMAs too; MOPS_F32 counts 512 flops-units per v_mfma_f32_16x16x4 (see r01_wino_pmc.txt)",
        "kernels": out}

@@ -658,9 +658,10 @@ class ACVNet_DDIM(_HipPlanMixin):
         return stack[-1]
 
     @torch.no_grad()
-    def encode_disparity(self, disp: torch.Tensor) -> torch.Tensor:
-        """x_T of acv_ddim.py:403-419 (mask_gt is None at every call site): quarter-resolution
-        disparity [B,1,h,w] -> [B,48,h,w] in [-1,1]."""
+    def encode_disparity(self, disp: torch.Tensor, mask_gt: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x_T of acv_ddim.py:403-419: quarter-resolution disparity [B,1,h,w] -> [B,48,h,w] in [-1,1].  `mask_gt` (None
+        at every call site of the reference; anything that broadcasts against [B,48,h,w]) puts the uniform distribution
+        1/48 where it is 0 (:415-417)."""
         disp = _dev_f32(disp, "disp")
         b, h, w = disp.shape[0], disp.shape[-2], disp.shape[-1]
         nb = self.maxdisp // 4
@@ -668,7 +669,20 @@ class ACVNet_DDIM(_HipPlanMixin):
         with torch.cuda.device(disp.device):
             _lib.check(_lib.load().dv_encode_two_hot_f32(disp.data_ptr(), x.data_ptr(), b, nb, h * w,
                                                          _lib.stream_ptr()), "dv_encode_two_hot_f32")
+        if mask_gt is not None:
+            # the reference selects before the *2-1 rescale; the same fp32 operations on the one constant it selects
+            uniform = ((torch.ones((), dtype=torch.float32, device=x.device) / nb) * 2 - 1) * self.scale
+            x = torch.where(mask_gt.to(x.device) == 0, uniform, x)
         return x
+
+    @torch.no_grad()
+    def attention_logits(self, feat_left: torch.Tensor, feat_right: torch.Tensor) -> torch.Tensor:
+        """acv_ddim.py:375-384 (= acv.py:171-197): gwc volume -> patch convs -> attention aggregation -> `att_weights`
+        [B,1,D/4,H/4,W/4]."""
+        p = self.prepare()
+        gwc = build_gwc_volume(feat_left, feat_right, self.maxdisp // 4, self.num_groups)
+        att = p.dres1_att(patch_volume(gwc, p.patch_w1, p.patch_w2, p.patch_dil))     # patch, patch_l1..3 (:377-381)
+        return p.classif_att(p.dres2_att(att))
 
     @torch.no_grad()
     def attention_concat_volume(self, feat_left: torch.Tensor, feat_right: torch.Tensor, lazy: bool = True):
@@ -677,9 +691,7 @@ class ACVNet_DDIM(_HipPlanMixin):
         (``AttentionConcatVolume``: the first aggregation layer reads nothing else, so the 3 GB tensor of :390 is
         not written); ``lazy=False`` returns the tensor."""
         p = self.prepare()
-        gwc = build_gwc_volume(feat_left, feat_right, self.maxdisp // 4, self.num_groups)
-        att = p.dres1_att(patch_volume(gwc, p.patch_w1, p.patch_w2, p.patch_dil))     # patch, patch_l1..3 (:377-381)
-        att = p.classif_att(p.dres2_att(att))
+        att = self.attention_logits(feat_left, feat_right)
         cl = p.concat_b(p.concat_a(feat_left))
         cr = p.concat_b(p.concat_a(feat_right))
         return build_concat_attention_volume(cl, cr, att, self.maxdisp // 4, lazy=lazy)
@@ -687,29 +699,27 @@ class ACVNet_DDIM(_HipPlanMixin):
     def forward(self, left, right, used, disp, mask_gt=None):
         if self.training:
             raise NotImplementedError("the MI355X DiffuVolume path is inference-only (model.eval())")
-        if mask_gt is not None:
-            raise NotImplementedError("mask_gt is None at every reference call site "
-                                      "(test_sceneflow_ddim.py:108); the masked x_T is not implemented")
         with torch.no_grad():
             self.prepare(check_weights=True)
             fl = self.feature_extraction(left)["gwc_feature"]
             fr = self.feature_extraction(right)["gwc_feature"]
             ac_volume = self.attention_concat_volume(fl, fr)
-            x_T = self.encode_disparity(disp)
+            x_T = self.encode_disparity(disp, mask_gt)
             pred, _ = self.ddim_sample(ac_volume, used, x_T)
         return [pred]
 
 
 class ACVNet(_HipPlanMixin):
-    """The origin network that supplies ``used`` (SceneFlow/models/acv.py:94-260, eval path with
-    attn_weights_only=False): same feature CNN, attention branch, concat volume and aggregation stack as
-    ACVNet_DDIM, run on the same HIP kernels, without the diffusion loop.  ``forward(left, right) -> [pred2]``.
-    Reference ``state_dict`` (561 keys) loads with strict=True."""
+    """The origin network that supplies ``used`` (SceneFlow/models/acv.py:94-260, eval path): same feature CNN, attention
+    branch, concat volume and aggregation stack as ACVNet_DDIM, run on the same HIP kernels, without the diffusion loop.
+    ``forward(left, right) -> [pred2]``, or ``[pred_attention]`` (the regression of the attention logits, acv.py:246-252)
+    when built with ``attn_weights_only=True`` -- the reference builds every module either way, so the ``state_dict``
+    (561 keys) is the same and loads with strict=True."""
 
     def __init__(self, maxdisp: int, attn_weights_only: bool = False, freeze_attn_weights: bool = False):
         super().__init__()
-        if maxdisp != 192 or attn_weights_only:
-            raise ValueError("ACVNet on the HIP path: maxdisp == 192 and attn_weights_only == False")
+        if maxdisp != 192:
+            raise ValueError("ACVNet on the HIP path: maxdisp == 192")
         self.maxdisp, self.attn_weights_only, self.freeze_attn_weights = maxdisp, attn_weights_only, freeze_attn_weights
         self.num_groups, self.concat_channels = 40, 32
         self.feature_extraction = FeatureExtraction()
@@ -733,6 +743,7 @@ class ACVNet(_HipPlanMixin):
         ACVNet_DDIM._init_weights(self)
         self._plans: Optional[_Plans] = None
 
+    attention_logits = ACVNet_DDIM.attention_logits
     attention_concat_volume = ACVNet_DDIM.attention_concat_volume
     _aggregate = ACVNet_DDIM._aggregate
 
@@ -743,7 +754,10 @@ class ACVNet(_HipPlanMixin):
             self.prepare(check_weights=True)
             fl = self.feature_extraction(left)["gwc_feature"]
             fr = self.feature_extraction(right)["gwc_feature"]
-            cost = self._aggregate(self.attention_concat_volume(fl, fr), None)
+            if self.attn_weights_only:                                           # acv.py:246-252
+                cost = self.attention_logits(fl, fr)
+            else:
+                cost = self._aggregate(self.attention_concat_volume(fl, fr), None)
             pred2, _ = upsample_softmax_regress(cost, want_uncertainty=False)
             if any_split_plan(self._plans):
                 check_split_overflow(pred2.device)

@@ -337,9 +337,14 @@ class ACVDiffusionOracle:
         cof = torch.tensor(self.cof).view(-1, 1, 1, 1)
         return torch.sum(stack * cof, dim=0), stack
 
-    def encode_x_T(self, disp_q: Tensor) -> Tensor:
-        """acv_ddim.py:403-419 (mask_gt is None at every call site)."""
-        return (encode_two_hot(disp_q, self.maxdisp // 4) * 2 - 1) * self.scale
+    def encode_x_T(self, disp_q: Tensor, mask_gt: Optional[Tensor] = None) -> Tensor:
+        """acv_ddim.py:403-419.  `mask_gt` (None at every call site of the reference) replaces the two-hot column by the
+        uniform distribution 1/48 wherever it is 0 (:415-417), before the *2-1 rescale."""
+        vol = encode_two_hot(disp_q, self.maxdisp // 4)
+        if mask_gt is not None:
+            allone = torch.ones_like(vol) / (self.maxdisp // 4)
+            vol = torch.where(mask_gt == 0, allone, vol)
+        return (vol * 2 - 1) * self.scale
 
 
 # --------------------------------------------------------------------------

@@ -24,5 +24,10 @@ ref.load_state_dict(synth_state_dict(ACVNet(192).state_dict(), seed=3, logit_gai
 batch = synth_stereo_batch(2, 64, 128, seed=42, shifts=(8, 20))
 with torch.no_grad():
     pred = ref(batch["left"], batch["right"])[-1]
-np.savez_compressed(REPO / "tests/golden/acv_origin_forward.npz", stereo_seed=42, pred=pred.numpy())
-print("acv_origin_forward.npz", tuple(pred.shape), float(pred.min()), float(pred.max()))
+# the same weights through the attention-only variant (acv.py:246-252: the regression of the attention logits)
+ref_att = REF_MODELS["acvnet"](192, True, False).eval()
+ref_att.load_state_dict(ref.state_dict(), strict=True)
+with torch.no_grad():
+    pred_att = ref_att(batch["left"], batch["right"])[-1]
+np.savez_compressed(REPO / "tests/golden/acv_origin_forward.npz", stereo_seed=42, pred=pred.numpy(), pred_attention=pred_att.numpy())
+print("acv_origin_forward.npz", tuple(pred.shape), float(pred.min()), float(pred.max()), float(pred_att.min()), float(pred_att.max()))

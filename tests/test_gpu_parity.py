@@ -657,6 +657,44 @@ def test_origin_acvnet_forward_golden():
     assert float(d.median()) < 1e-4 and float(d.mean()) < 1e-3, (float(d.median()), float(d.mean()))
 
 
+def test_origin_acvnet_attention_only_golden():
+    """ACVNet(192, attn_weights_only=True): the regression of the attention logits (acv.py:246-252), same state_dict."""
+    from diffuvolume_amd import ACVNet
+    g = load_golden("acv_origin_forward")
+    m = ACVNet(192, True, False)
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed=3, logit_gain=8.0), strict=True)
+    m = m.to(DEV).eval()
+    batch = synth_stereo_batch(2, 64, 128, seed=g["stereo_seed"], shifts=(8, 20))
+    out = m(dev(batch["left"]), dev(batch["right"]))
+    assert len(out) == 1 and out[0].shape == g["pred_attention"].shape
+    d = (out[0].cpu() - g["pred_attention"]).abs()
+    assert float(d.median()) < 1e-4 and float(d.mean()) < 1e-3, (float(d.median()), float(d.mean()))
+    assert float((out[0].cpu() - g["pred"]).abs().mean()) > 1e-2          # and it is not the full network's output
+
+
+def test_masked_x_T_golden(model):
+    """`mask_gt` given (acv_ddim.py:415-417): x_T bit for bit against what the reference's forward hands to ddim_sample,
+    and forward() passes the mask through."""
+    g = load_golden("acv_xT_masked")
+    x = model.encode_disparity(dev(g["disp"]), dev(g["mask_gt"]))
+    assert torch.equal(x.cpu(), g["x_T_masked"])
+    assert torch.equal(model.encode_disparity(dev(g["disp"])).cpu(), g["x_T"])
+    assert torch.equal(model.encode_disparity(dev(g["disp"]), g["mask_gt"].bool()).cpu(), g["x_T_masked"])    # bool mask, host tensor
+    batch = synth_stereo_batch(2, 64, 128, seed=43, shifts=(8, 20))
+    keep, seen = model.ddim_sample, {}
+
+    def spy(v, u, a, **kw):
+        seen["x_T"] = a
+        return u, None
+
+    model.ddim_sample = spy
+    try:
+        model(dev(batch["left"]), dev(batch["right"]), dev(batch["used"]), dev(g["disp"]), dev(g["mask_gt"]))
+    finally:
+        del model.ddim_sample
+    assert keep is not None and torch.equal(seen["x_T"].cpu(), g["x_T_masked"])
+
+
 def test_split_fp16_range_guard():
     """Activations beyond the fp16 range must not pass silently: the kernel raises a device flag and the
     wrapper turns it into an error (no quiet garbage, no quiet fallback)."""

@@ -74,6 +74,16 @@ def test_encoder_and_schedule():
     assert O.ddim_time_pairs(1000, 5) == [(999, 799), (799, 599), (599, 399), (399, 199), (199, -1)]
 
 
+def test_masked_x_T():
+    """acv_ddim.py:415-417, the `mask_gt` variant of x_T (None at every call site, but part of the signature): the
+    reference's own forward recorded what it hands to ddim_sample (oracle/make_golden_xT_masked.py)."""
+    g = load_golden("acv_xT_masked")
+    orc = O.ACVDiffusionOracle({})
+    close(orc.encode_x_T(g["disp"]), g["x_T"])
+    close(orc.encode_x_T(g["disp"], g["mask_gt"]), g["x_T_masked"])
+    assert 0.2 < float((g["x_T_masked"] != g["x_T"]).float().mean()) < 0.5          # the mask does something
+
+
 def test_time_shift(acv_state_dict):
     g = load_golden("time_shift")
     shift = O.time_shift(g["t"], acv_state_dict)

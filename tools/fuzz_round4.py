@@ -64,5 +64,31 @@ for i in range(n):
     if not (e < 2e-6 and torch.equal(vol, lazy.tensor())):
         bad += 1
         print("  BAD concat", e, bool(torch.equal(vol, lazy.tensor())))
+    # ---- stride-2 convolution: both tilings, the default choice, with and without the filter prologue, a residual
+    import os
+    cin, cout = random.choice([1, 4, 8, 12, 32, 64]), random.choice([16, 24, 32, 64, 72, 128])
+    bs, ds, hs, ws = random.choice([1, 2, 3]), random.randint(1, 11), random.randint(1, 20), random.choice([1, 2, 7, 31, 32, 33, 63, 64, 65, 120])
+    print("S2", i, bs, cin, cout, ds, hs, ws, flush=True)
+    xs2 = torch.randn(bs, cin, ds, hs, ws, device=dev)
+    ws2 = torch.randn(cout, cin, 3, 3, 3, device=dev) * (2.0 / (27 * cin)) ** 0.5
+    bn = tuple(t.to(dev) for t in (torch.rand(cout) + 0.5, torch.randn(cout) * 0.1, torch.randn(cout) * 0.1, torch.rand(cout) + 0.5))
+    flt = torch.rand(bs, ds, hs, ws, device=dev) if random.random() < 0.5 else None
+    xin = xs2.double() if flt is None else xs2.double() * flt.double().unsqueeze(1)
+    ref = F.batch_norm(F.conv3d(xin, ws2.double(), None, 2, 1), bn[2].double(), bn[3].double(), bn[0].double(), bn[1].double(), False, 0.0, 1e-5)
+    res = torch.randn(ref.shape, device=dev) if random.random() < 0.5 else None
+    ref = torch.relu(ref if res is None else ref + res.double())
+    plan = S.Conv3dPlan(ws2, bn, stride=2, act=S.ACT_RELU)
+    outs = []
+    for pin in ("big", "small", None):
+        if pin is None:
+            os.environ.pop("DV_S2_TILE", None)
+        else:
+            os.environ["DV_S2_TILE"] = pin
+        outs.append(plan(xs2, in_scale=flt, residual=res).clone())
+    os.environ.pop("DV_S2_TILE", None)
+    e = rel(outs[0], ref)
+    if not (e < 2e-5 and torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])):
+        bad += 1
+        print("  BAD stride2", e, bool(torch.equal(outs[0], outs[1])), bool(torch.equal(outs[0], outs[2])))
 print("failures:", bad)
 sys.exit(1 if bad else 0)

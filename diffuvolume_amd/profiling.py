@@ -34,6 +34,7 @@ class KernelTimer:
         return out
 
 
+S2PP_MULT_REDUCTION = 1.44     # polyphase F(2,2) stride-2 form: 25 multiplies per 2x2 outputs and (depth tap, channel) instead of 36
 WINO_MULT_REDUCTION = 2.25     # F(2x2,3x3): 16 multiplies per 2x2 outputs and (depth tap, channel) instead of 36
 
 

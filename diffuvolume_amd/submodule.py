@@ -12,12 +12,13 @@ runs on the MI355X or raises.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Tuple
 
 import torch
 
 from . import _lib
-from .profiling import WINO_MULT_REDUCTION, timed
+from .profiling import S2PP_MULT_REDUCTION, WINO_MULT_REDUCTION, timed
 
 __all__ = ["build_gwc_volume", "build_concat_volume", "build_concat_attention_volume", "AttentionConcatVolume",
            "volume_factors",
@@ -373,7 +374,17 @@ class Conv3dPlan:
         self.split = precision == "f16x3" and k == 3 and stride == 1 and self.cout > 1
         self.wino = precision == "f32" and k == 3 and stride == 1 and self.cout > 1
         lib = _lib.load()
+        # 3x3x3 stride 2, 64 output channels per block: the polyphase minimal-filtering form (csrc/conv3d_s2pp.hip);
+        # a call with a filter prologue falls back to the direct kernel (both weight images are kept)
+        self.s2pp = (precision == "f32" and k == 3 and stride == 2 and os.environ.get("DV_S2PP", "1") != "0"
+                     and bool(lib.dv_conv3d_s2pp_supported(self.cin, self.cout, 4, 4, 4)))
         with torch.cuda.device(w.device):
+            if self.s2pp:
+                self.wpacked_pp = torch.empty(lib.dv_conv3d_s2pp_packed_floats(self.cin, self.cout), dtype=torch.float32,
+                                              device=w.device)
+                _lib.check(lib.dv_conv3d_s2pp_pack_weights_f32(w.data_ptr(), self.wpacked_pp.data_ptr(), self.cin,
+                                                               self.cout, _lib.stream_ptr()),
+                           "dv_conv3d_s2pp_pack_weights_f32")
             if self.wino:
                 n = lib.dv_conv3d_wino_packed_floats(self.cin, self.cout)
                 self.wpacked = torch.empty(n, dtype=torch.float32, device=w.device)
@@ -442,6 +453,15 @@ class Conv3dPlan:
                                                                 out.data_ptr(), b, cin, d, h, w, self.cout,
                                                                 self.act, _lib.stream_ptr()),
                                          "dv_conv3d_wino_f32"), issued=2.0 * out.numel() * cin * 27 / WINO_MULT_REDUCTION)
+                return out
+            if self.s2pp and in_scale is None and x.data_ptr() % 16 == 0 and \
+                    lib.dv_conv3d_s2pp_supported(cin, self.cout, d, h, w):
+                timed(f"conv3d_k3s2_co{self.cout}", 2.0 * out.numel() * cin * 27, nb,
+                      lambda: _lib.check(lib.dv_conv3d_s2pp_f32(x.data_ptr(), self.wpacked_pp.data_ptr(),
+                                                                _lib.ptr(self.scale), _lib.ptr(self.shift),
+                                                                _lib.ptr(residual), out.data_ptr(), b, cin, d, h, w,
+                                                                self.cout, self.act, _lib.stream_ptr()),
+                                         "dv_conv3d_s2pp_f32"), issued=2.0 * out.numel() * cin * 27 / S2PP_MULT_REDUCTION)
                 return out
             timed(f"conv3d_k{self.k}s{self.stride}_co{self.cout}" + ("" if in_scale is None else "_filter"),
                   2.0 * out.numel() * cin * self.k ** 3, nb,

@@ -136,6 +136,24 @@ int dv_conv3d_wino_f32(const float* in, const float* wpacked, const float* ch_sc
                        const float* in_scale, const float* residual, float* out,
                        int B, int Cin, int D, int H, int W, int Cout, int act, dv_stream_t stream);
 
+/* The 3x3x3 STRIDE-2 layer (hourglass conv1 / conv3: acv_ddim.py:60,:66; pwcnet_ddim.py:137-147) in its polyphase
+ * minimal-filtering form (csrc/conv3d_s2pp.hip): per in-plane axis the odd input phase sees a 2-tap filter, done as
+ * F(2,2), the even phase one tap -- 25 instead of 36 multiplies per 2x2 outputs, depth taps direct, still on
+ * v_mfma_f32_16x16x4_f32 with fp32 operands and accumulation.  The transforms only subtract (weights are summed once
+ * by the pack), so results differ from dv_conv3d_f32(stride = 2) by fp32 rounding of one extra subtraction per operand.
+ *   y = act( conv_s2(in) * ch_scale[co] + ch_bias[co] + residual )
+ * 64 output channels per block and rows that travel as 16-byte quads: dv_conv3d_s2pp_supported says whether a layer
+ * qualifies (Cout a multiple of 64, W a multiple of 4, D*H*W*4 <= 2^30; `in` 16-byte aligned), dv_conv3d_s2pp_f32 returns
+ * DV_ERR_UNSUPPORTED otherwise.  Persistent launch: two blocks per CU walk the tile list.
+ * `wpacked` from dv_conv3d_s2pp_pack_weights_f32. */
+int dv_conv3d_s2pp_supported(int Cin, int Cout, int D, int H, int W);
+size_t dv_conv3d_s2pp_packed_floats(int Cin, int Cout);
+int dv_conv3d_s2pp_pack_weights_f32(const float* w /*[Cout,Cin,3,3,3]*/, float* wpacked, int Cin, int Cout,
+                                    dv_stream_t stream);
+int dv_conv3d_s2pp_f32(const float* in, const float* wpacked, const float* ch_scale, const float* ch_bias,
+                       const float* residual, float* out,
+                       int B, int Cin, int D, int H, int W, int Cout, int act, dv_stream_t stream);
+
 /* nn.ConvTranspose3d(k=3, stride=2, padding=1, output_padding=1, bias=False) + BN
  * + skip add + activation: acv_ddim.py:74-80 and :91-92.  w [Cin,Cout,3,3,3].
  * in [B,Cin,D,H,W] -> out [B,Cout,2D,2H,2W]. */

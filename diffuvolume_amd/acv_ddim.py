@@ -685,11 +685,12 @@ class ACVNet_DDIM(_HipPlanMixin):
         return p.classif_att(p.dres2_att(att))
 
     @torch.no_grad()
-    def attention_concat_volume(self, feat_left: torch.Tensor, feat_right: torch.Tensor, lazy: bool = True):
+    def attention_concat_volume(self, feat_left: torch.Tensor, feat_right: torch.Tensor, lazy: bool = False):
         """acv_ddim.py:375-390: gwc volume -> patch convs -> attention aggregation -> logits, then the
-        softmax-weighted concat volume (the tensor the DDIM loop filters) -- by default as its factors
-        (``AttentionConcatVolume``: the first aggregation layer reads nothing else, so the 3 GB tensor of :390 is
-        not written); ``lazy=False`` returns the tensor."""
+        softmax-weighted concat volume (the tensor the DDIM loop filters), [B,64,D/4,H/4,W/4] like the reference's :390.
+        ``lazy=True`` (what ``forward`` passes) returns its factors instead (``AttentionConcatVolume``: the first
+        aggregation layer reads nothing else, so the 3 GB tensor is not written) -- same default as
+        ``build_concat_attention_volume``, so a caller who indexes / clones the result gets a tensor."""
         p = self.prepare()
         att = self.attention_logits(feat_left, feat_right)
         cl = p.concat_b(p.concat_a(feat_left))
@@ -703,7 +704,7 @@ class ACVNet_DDIM(_HipPlanMixin):
             self.prepare(check_weights=True)
             fl = self.feature_extraction(left)["gwc_feature"]
             fr = self.feature_extraction(right)["gwc_feature"]
-            ac_volume = self.attention_concat_volume(fl, fr)
+            ac_volume = self.attention_concat_volume(fl, fr, lazy=True)
             x_T = self.encode_disparity(disp, mask_gt)
             pred, _ = self.ddim_sample(ac_volume, used, x_T)
         return [pred]
@@ -757,7 +758,7 @@ class ACVNet(_HipPlanMixin):
             if self.attn_weights_only:                                           # acv.py:246-252
                 cost = self.attention_logits(fl, fr)
             else:
-                cost = self._aggregate(self.attention_concat_volume(fl, fr), None)
+                cost = self._aggregate(self.attention_concat_volume(fl, fr, lazy=True), None)
             pred2, _ = upsample_softmax_regress(cost, want_uncertainty=False)
             if any_split_plan(self._plans):
                 check_split_overflow(pred2.device)

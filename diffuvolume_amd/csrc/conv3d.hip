@@ -17,11 +17,15 @@
 
 #include <type_traits>
 
+#include <atomic>
 #include <cstdlib>
 
 #include "dv_common.h"
 
 namespace {
+
+// test hook: 0 = the launcher picks the stride-2 tiling, 1 = 2 x 4 x 32 tiles, 2 = 2 x 2 x 32 tiles (dv_conv3d_set_s2_tile)
+std::atomic<int> g_s2_tile_pin{0};
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -725,6 +729,12 @@ int launch_conv(ConvArgs a, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int dv_conv3d_set_s2_tile(int mode) {
+  if (mode < 0 || mode > 2) return DV_ERR_UNSUPPORTED;
+  g_s2_tile_pin.store(mode, std::memory_order_relaxed);
+  return DV_OK;
+}
+
 extern "C" size_t dv_conv3d_packed_floats(int Cin, int Cout, int k) {
   if (Cin <= 0 || Cout <= 0 || (k != 1 && k != 3)) return 0;
   if (Cout == 1 && k == 3) return (size_t)pad_to(Cin * 27, 4);      // vector-ALU path: raw [Cin][27]
@@ -802,10 +812,10 @@ extern "C" int dv_conv3d_f32(const float* in, const float* wpacked, const float*
     // on 2 x 2 x 32 tiles at three blocks per CU (53.6 KB of LDS, 135 VGPRs): 0.730 -> 0.700 ms at batch 8; the 32 -> 64
     // layers (768 blocks per pair) are unchanged by it (profiles/r04_kernel_experiments.txt).  The choice looks at one
     // batch item only and both tilings sum every output in the same order (chunk by chunk, tap by tap), so a shard of a
-    // batch reproduces the batch's bits.  DV_S2_TILE=big|small pins it (tests).
-    const char* pin = getenv("DV_S2_TILE");          // (read per launch: the tests flip it inside one process)
+    // batch reproduces the batch's bits.  dv_conv3d_set_s2_tile pins it (tests).
+    const int pin = g_s2_tile_pin.load(std::memory_order_relaxed);      // dv_conv3d_set_s2_tile (tests)
     const long long per_item = (long long)(a.Coutp / 64) * ((a.Do + 1) / 2) * ((a.Ho + 3) / 4) * ((a.Wo + 31) / 32);
-    const bool small = pin ? pin[0] == 's' : per_item < 512;
+    const bool small = pin ? pin == 2 : per_item < 512;
     if (small) return launch_conv<Geo<3, 2, 4, 2, 2, 2, 4, 3>>(a, s);
     return launch_conv<Geo<3, 2, 4, 2, 4, 2, 4, 2>>(a, s);
   }

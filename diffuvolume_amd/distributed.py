@@ -20,6 +20,10 @@ def init_from_env(backend: str | None = None, force: bool = False) -> Tuple[int,
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if (world > 1 or force) and not dist.is_initialized():
+        if world > 1 and not ("RANK" in os.environ and "MASTER_PORT" in os.environ):
+            # a bare WORLD_SIZE (a scheduler's export): every process would join as rank 0 and wait for the others forever
+            raise RuntimeError(f"WORLD_SIZE={world} without RANK / MASTER_PORT: not a launcher environment (use torchrun, or "
+                               "`python bench.py --gpus N`, which starts its own ranks)")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

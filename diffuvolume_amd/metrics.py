@@ -4,9 +4,11 @@ the GPUs of a node.
 The reference evaluates each metric image by image with boolean-index gathers and one
 ``.item()`` sync per metric.  Here one HIP pass yields seven per-image sums
 (``dv_masked_metrics_f32``); the reference's semantics (per-image mean, images whose mask
-ratio is < 0.1 skipped, batch value = mean over kept images, run value = mean over batches:
-metrics.py:30-40 + experiment.py:146-151) are applied to those sums.  Across ranks only
-the 6 x fp64 running sums are all-reduced (RCCL over xGMI), once.
+ratio is < 0.1 skipped, batch value = mean over the kept images of the GLOBAL batch, run value =
+mean over batches: metrics.py:30-40 + experiment.py:146-151) are applied to those sums.  Across
+ranks only [sum of per-image values x 5, kept images] per batch is all-reduced (fp64, 48 bytes per
+batch, RCCL over xGMI), once, BEFORE the per-batch division -- so a rank that skips an image gives the
+single-process number.
 """
 from __future__ import annotations
 
@@ -72,26 +74,54 @@ def Thres_metric(D_est, D_gt, mask, thres):
     return batch_metrics(D_est, D_gt, mask)[f"Thres{int(thres)}"]
 
 
+def kept_sums(sums: torch.Tensor) -> torch.Tensor:
+    """sums [B,8] (``image_sums``) -> fp64 [6] = [sum of the per-image EPE, D1, Thres1, Thres2, Thres3 over the KEPT images of
+    this (shard of a) batch, number of kept images] -- the vector SURVEY 8(e) all-reduces."""
+    vals, keep = per_image_values(sums)
+    k = keep.to(vals.dtype)
+    return torch.cat([(vals * k[:, None]).sum(0), k.sum().reshape(1)])
+
+
 class MetricAccumulator:
-    """AverageMeterDict semantics (experiment.py:126-151: mean over *batches* of the per-batch
-    means) kept as fp64 sums on the device; ``reduce()`` all-reduces them over the process
-    group (one 48-byte SUM, RCCL on GPUs / gloo in the CPU tests)."""
+    """The reference's metric bookkeeping across batches AND ranks (SceneFlow/utils/metrics.py:22-41 +
+    utils/experiment.py:126-151), kept as fp64 sums on the device:
+
+    * one global batch = the shards all ranks hold of it (the reference's nn.DataParallel scatters every batch over the
+      GPUs and evaluates the metric on the gathered output).  Per batch every rank records ``kept_sums`` of ITS images:
+      5 sums of per-image values over the images it keeps + how many it kept (an image whose mask ratio is < 0.1 is
+      skipped, metrics.py:30-31);
+    * ``reduce()`` all-reduces the [n_batches, 6] table ONCE (SUM; 48 bytes per batch, RCCL on GPUs / gloo in the CPU
+      tests) and only then forms the reference's numbers: batch value = sum / kept images of the GLOBAL batch (0 if all
+      were skipped, metrics.py:36-38), run value = mean over batches (AverageMeterDict).  A rank that skips an image
+      therefore changes the divisor of that batch exactly as it does in the single-process run.
+
+    Every rank records the same number of batches (each global batch is sharded over all ranks)."""
 
     def __init__(self, device):
-        self.state = torch.zeros(6, dtype=torch.float64, device=device)   # 5 metric sums + batch count
+        self.device = torch.device(device)
+        self.rows = []                                      # one fp64 [6] per batch, on the device
 
-    def update(self, batch: Dict[str, torch.Tensor]) -> None:
-        vals = torch.stack([batch[n].double() for n in NAMES])
-        self.state[:5] += vals.to(self.state.device)
-        self.state[5] += 1
+    def update_sums(self, sums: torch.Tensor) -> None:
+        """``sums`` = ``image_sums(est, gt, mask)`` of this rank's shard of one batch."""
+        self.rows.append(kept_sums(sums.to(self.device, torch.float64)))
+
+    def update_images(self, est: torch.Tensor, gt: torch.Tensor, mask: torch.Tensor) -> None:
+        self.update_sums(image_sums(est, gt, mask))
+
+    def table(self) -> torch.Tensor:
+        return torch.stack(self.rows) if self.rows else torch.zeros((0, 6), dtype=torch.float64, device=self.device)
 
     def reduce(self, group=None) -> Dict[str, float]:
         import torch.distributed as dist
-        state = self.state.clone()
+        table = self.table().clone()
         if dist.is_available() and dist.is_initialized():     # also a one-rank group: same RCCL path as N ranks
             if dist.get_backend(group) == "gloo":          # CPU rendezvous (tests on a 1-GPU box): reduce on the host
-                state = state.cpu()
-            dist.all_reduce(state, op=dist.ReduceOp.SUM, group=group)
-        host = state.cpu()
-        n = max(float(host[5]), 1.0)
-        return {name: float(host[i]) / n for i, name in enumerate(NAMES)}
+                table = table.cpu()
+            dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
+        host = table.cpu()
+        if host.shape[0] == 0:
+            return {name: 0.0 for name in NAMES}
+        kept = host[:, 5:6]
+        per_batch = torch.where(kept > 0, host[:, :5] / kept.clamp(min=1.0), torch.zeros_like(host[:, :5]))
+        mean = per_batch.mean(0)
+        return {name: float(mean[i]) for i, name in enumerate(NAMES)}

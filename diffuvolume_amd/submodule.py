@@ -1002,7 +1002,8 @@ def patch_volume(gwc: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, dilation
     if tuple(w1.shape) != (g, 9) or tuple(w2.shape) != (g, 9) or dilation.numel() != g or dilation.dtype != torch.int32:
         raise RuntimeError("w1 / w2 must be [G,9] and dilation [G] int32")
     runs = getattr(dilation, "_dv_runs", None)
-    if runs is None or runs[0] != dilation._version:
+    key = (dilation.data_ptr(), dilation._version)       # (a `.data` swap keeps _version: the pointer is part of the key)
+    if runs is None or runs[0] != key:
         vals, r = dilation.detach().cpu().tolist(), []
         for i, v in enumerate(vals):
             if r and r[-1][2] == v:
@@ -1010,7 +1011,7 @@ def patch_volume(gwc: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, dilation
             else:
                 r.append([i, 1, v])
         arr = lambda k: (ctypes.c_int * len(r))(*[x[k] for x in r])
-        runs = (dilation._version, len(r), arr(0), arr(1), arr(2), all(1 <= x[2] <= 3 for x in r))
+        runs = (key, len(r), arr(0), arr(1), arr(2), all(1 <= x[2] <= 3 for x in r))
         dilation._dv_runs = runs
     out = torch.empty_like(gwc)
     lib = _lib.load()

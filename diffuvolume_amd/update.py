@@ -122,8 +122,8 @@ class BasicMotionEncoder(_Planned):
     def _convd1(self, disp):
         """relu(convd1(disp)): the 7x7 single-input-channel convolution on its own VALU kernel (MIOpen picks a naive
         solver for this shape: 0.7 ms per call at batch 4)."""
-        if not _hip_ok(disp):
-            return F.relu(self.convd1(disp))
+        if not _hip_ok(disp, "convd1"):
+            return F.relu(self.convd1(disp))                 # autograd dispatch (training graphs only)
         disp = disp.contiguous()
         b, _, h, w = disp.shape
         out = torch.empty((b, self.convd1.out_channels, h, w), dtype=torch.float32, device=disp.device)
@@ -135,14 +135,24 @@ class BasicMotionEncoder(_Planned):
         return out
 
 
-def _hip_ok(x):
-    return x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and x.requires_grad)
+def _hip_ok(x, what):
+    """True: the HIP kernel runs.  False: the caller asked for gradients (grad enabled AND the tensor requires grad), the
+    one case that is dispatched to the differentiable torch expression -- explicitly, like submodule.py's builders.
+    Anything else (a CPU tensor, another dtype) RAISES: there is no silent eager / CPU fallback on the product path."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        return False
+    if not x.is_cuda:
+        raise _lib.DiffuVolumeError(f"{what}: input is on {x.device}; the DiffuVolume hot path only runs on the MI355X "
+                                    "(HIP kernels, no CPU fallback)")
+    if x.dtype != torch.float32:
+        raise TypeError(f"{what}: input must be float32, got {x.dtype}")
+    return True
 
 
 def pool2x(x):
-    """update.py:96-97.  HIP (`dv_avg_pool3s2_f32`) for CUDA fp32 inference tensors."""
-    if not _hip_ok(x):
-        return F.avg_pool2d(x, 3, stride=2, padding=1)
+    """update.py:96-97.  HIP (`dv_avg_pool3s2_f32`); the torch expression only when gradients are asked for."""
+    if not _hip_ok(x, "pool2x"):
+        return F.avg_pool2d(x, 3, stride=2, padding=1)     # autograd dispatch
     x = x.contiguous()
     b, c, h, w = x.shape
     out = torch.empty((b, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1), dtype=torch.float32, device=x.device)
@@ -157,9 +167,9 @@ def pool4x(x):
 
 
 def interp(x, dest):
-    """update.py:100-102.  HIP (`dv_resize_bilinear_ac_f32`) for CUDA fp32 inference tensors."""
-    if not _hip_ok(x):
-        return F.interpolate(x, dest.shape[2:], mode="bilinear", align_corners=True)
+    """update.py:100-102.  HIP (`dv_resize_bilinear_ac_f32`); the torch expression only when gradients are asked for."""
+    if not _hip_ok(x, "interp"):
+        return F.interpolate(x, dest.shape[2:], mode="bilinear", align_corners=True)     # autograd dispatch
     x = x.contiguous()
     b, c, h, w = x.shape
     H, W = int(dest.shape[2]), int(dest.shape[3])

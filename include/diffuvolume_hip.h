@@ -112,6 +112,10 @@ int dv_conv3d_f32(const float* in, const float* wpacked, const float* ch_scale, 
                   int B, int Cin, int D, int H, int W, int Cout, int k, int stride, int act,
                   dv_stream_t stream);
 
+/* Test hook: pins the tiling of the DIRECT stride-2 kernel (0 = the launcher's own choice from the size of one batch item,
+ * 1 = 2 x 4 x 32 output tiles, 2 = 2 x 2 x 32); both tilings give the same bits.  Process-wide; returns DV_OK. */
+int dv_conv3d_set_s2_tile(int mode);
+
 /* The same 3x3x3 stride-1 layer (Cout <= 32) on the fp16 matrix instruction with every fp32 operand
  * carried as hi+lo fp16 pairs: x*w ~= hi*hi' + hi*lo' + lo*hi', fp32 accumulate (csrc/conv3d_f16x3.hip).
  * Split error 2^-22 per operand, below the fp32 accumulation rounding; opt-in (DV_CONV_PRECISION=f16x3).

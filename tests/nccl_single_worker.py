@@ -21,7 +21,8 @@ def main():
     t = torch.arange(6, dtype=torch.float64, device=dev)
     dist.all_reduce(t)                                   # a device buffer through RCCL
     acc = M.MetricAccumulator(dev)
-    acc.update({n: torch.tensor(float(i + 1), device=dev) for i, n in enumerate(M.NAMES)})
+    # one image, 10 masked pixels: per-image values 1, 2, 3, 4, 5 (sums n_mask, n_gt>0, sum|err|, n_D1, n_>1, n_>2, n_>3, 0)
+    acc.update_sums(torch.tensor([[10.0, 10.0, 10.0, 20.0, 30.0, 40.0, 50.0, 0.0]], dtype=torch.float64, device=dev))
     red = acc.reduce()
     mx = D.barrier_and_max(0.125, dev)
     dist.barrier()

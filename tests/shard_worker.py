@@ -26,8 +26,9 @@ def shard_epe(model, x, gt, lo, hi, dev, acc, batch=8, seed=5):
         vol = dv.build_concat_attention_volume(s["cl"], s["cr"], s["att"], 48)
         final, _ = model.ddim_sample(vol, s["used"], model.encode_disparity(s["dq"]), noise=draw)
         g = gt[lo:hi].to(dev)
-        acc.update(M.batch_metrics(final, g, (g < 192) & (g > 0)))
-    return final, float(gwc.double().sum())
+        sums = M.image_sums(final, g, (g < 192) & (g > 0))
+        acc.update_sums(sums)                              # this rank's shard of the one global batch
+    return final, float(gwc.double().sum()), sums
 
 
 def build(dev):
@@ -49,7 +50,7 @@ def main():
     model, x, gt = build(dev)
     lo, hi = D.shard_range(8, rank, world)
     acc = M.MetricAccumulator(dev)
-    final, gsum = shard_epe(model, x, gt, lo, hi, dev, acc)
+    final, gsum, _ = shard_epe(model, x, gt, lo, hi, dev, acc)
     out = acc.reduce()                                  # the one collective of the path
     print(json.dumps({"rank": rank, "lo": lo, "hi": hi, "metrics": out, "final_sum": float(final.double().sum()),
                       "final_hex": final.double().sum().item().hex(), "gwc_sum": gsum}), flush=True)

@@ -74,8 +74,40 @@ def test_under_torchrun_two_ranks():
 
 
 def test_world_size_mismatch_is_an_error():
-    r = _run(["--gpus", "4", "--dry-run"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    r = _run(["--gpus", "4", "--dry-run"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_PORT": "29654"})
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_a_bare_world_size_neither_blocks_the_self_launch_nor_hangs():
+    """with a scheduler-exported WORLD_SIZE (no RANK / MASTER_PORT) `--gpus N` still starts its own ranks --
+    WORLD_SIZE=1 used to die with a mismatch, WORLD_SIZE=N used to join N processes as rank 0 and hang."""
+    for ws in ("1", "2"):
+        r = _run(["--gpus", "2", "--dry-run"], env={"WORLD_SIZE": ws})
+        assert r.returncode == 0, r.stderr
+        line = _json_line(r.stdout)
+        assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["launcher"] == "self"
+    from diffuvolume_amd import distributed as D
+    import pytest
+    old = {k: os.environ.pop(k, None) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    try:
+        os.environ["WORLD_SIZE"] = "8"
+        with pytest.raises(RuntimeError, match="not a launcher environment"):
+            D.init_from_env(backend="gloo")
+    finally:
+        os.environ.pop("WORLD_SIZE", None)
+        for k, v in old.items():
+            if v is not None:
+                os.environ[k] = v
+
+
+def test_every_workload_launches_eight_ranks():
+    """BASELINE configs 3 / 4 / 5 through the same launcher and the same contract line: `--workload` names the config, the
+    per-GPU batch follows it (8 / 4 / 4 pairs)."""
+    for wl, gb in (("kitti12", 32), ("kitti15", 32)):
+        r = _run(["--gpus", "8", "--dry-run", "--workload", wl], timeout=300)
+        assert r.returncode == 0, r.stderr
+        line = _json_line(r.stdout)
+        assert line["workload"] == wl and line["n_gpus"] == 8 and line["ranks"] == 8 and line["global_batch"] == gb
 
 
 def test_too_few_devices_is_an_error():

@@ -1078,27 +1078,26 @@ print("OK", h.hexdigest())
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 128, 8, 12, 60), (1, 32, 64, 6, 9, 37), (1, 16, 64, 4, 8, 64)])
-def test_stride2_tilings_give_the_same_bits(shape):
-    """The stride-2 convolution picks 2 x 4 x 32 or 2 x 2 x 32 output tiles from the size of ONE batch item (csrc/conv3d.hip);
-    both sum every output chunk by chunk, tap by tap, so the choice may not change a bit -- what lets a shard of a batch
-    reproduce the batch (section 6 of DESIGN.md).  Also against F.conv3d."""
-    import os
+def test_stride2_tilings_give_the_same_bits(shape, monkeypatch):
+    """The DIRECT stride-2 convolution picks 2 x 4 x 32 or 2 x 2 x 32 output tiles from the size of ONE batch item
+    (csrc/conv3d.hip); both sum every output chunk by chunk, tap by tap, so the choice may not change a bit -- what lets a
+    shard of a batch reproduce the batch (section 6 of DESIGN.md).  Also against F.conv3d.  (DV_S2PP=0: the layers the
+    polyphase kernel takes since round 5 would not reach the direct kernel otherwise.)"""
+    from diffuvolume_amd import _lib
+    monkeypatch.setenv("DV_S2PP", "0")
     b, cin, cout, d, h, w = shape
     g = _gen(191, str(shape))
     x = torch.randn(b, cin, d, h, w, generator=g)
     wt = torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5
     plan = S.Conv3dPlan(dev(wt), None, stride=2, act=S.ACT_RELU)
+    assert not plan.s2pp
     outs = {}
-    old = os.environ.get("DV_S2_TILE")
     try:
-        for tile in ("big", "small"):
-            os.environ["DV_S2_TILE"] = tile
+        for mode, tile in ((1, "big"), (2, "small")):
+            assert _lib.load().dv_conv3d_set_s2_tile(mode) == 0
             outs[tile] = plan(dev(x)).clone()
     finally:
-        if old is None:
-            os.environ.pop("DV_S2_TILE", None)
-        else:
-            os.environ["DV_S2_TILE"] = old
+        _lib.load().dv_conv3d_set_s2_tile(0)
     assert torch.equal(outs["big"], outs["small"])
     ref = torch.relu(torch.nn.functional.conv3d(x.double(), wt.double(), None, 2, 1)).float()
     assert rel_err(outs["small"], ref) < 1e-5

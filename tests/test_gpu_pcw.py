@@ -84,6 +84,7 @@ def test_model_predictions_golden(model):
     print(f"pcw model_predictions, unconditioned network (diagnostic): mean {float(d.mean()):.2e} px, share beyond 1e-3 px "
           f"{float((d > 1e-3).float().mean()):.2e}, max {float(d.max()):.2e}")
     assert float(d.mean()) < 3e-4, (float(d.mean()), float(d.max()))
+    assert float(torch.quantile(d.flatten(), 0.99)) < 2e-2, float(torch.quantile(d.flatten(), 0.99))     # loose, but a bound
     assert float((handle.uncertainty.cpu() - g["unc"]).abs().mean()) < 2e-3
 
 
@@ -112,15 +113,32 @@ def _assert_pcw_loop_contract(model, sd, vol, used, asd, fl, fr, seed, gt=None, 
         assert s["epe_delta"] < LP.BAR_EPE, s
         if raw and split[i]["warp_mask_flips"] == 0:
             assert s["frac_gt_1e-3"] <= bar, s                    # the contract's figure, all pixels, no scaling
-    for s in (df if flips == 0 or not raw else []) + (fr_["steps"] if flips == 0 else []):
-        if raw:
-            assert s["frac_gt_1e-3"] <= bar and s["epe_delta"] < LP.BAR_EPE, s
-        else:                                                     # diagnostic network: divergence bound only
-            assert s["epe_delta"] < 1e-3 and s["mean_abs_px"] < 1e-2, s
+        elif not raw:                                             # diagnostic network: a loose quantile, still a bound
+            assert s["frac_gt_1e-3"] <= 0.10 and s["mean_abs_px"] < 2e-3, s
+    # Decision-forced steps run under the ORACLE's renewal decisions: a flip of the free run does not excuse them.  Raw
+    # bars whenever the warp-validity masks of that step agree (a flipped mask pixel moves its +-61-pixel neighbourhood,
+    # DESIGN 2.2); the divergence bound that has held on every box otherwise and on the diagnostic network.
+    for i, s in enumerate(df):
+        if raw and split[i]["warp_mask_flips"] == 0:
+            assert s["frac_gt_1e-3"] <= bar and s["epe_delta"] < LP.BAR_EPE, ("decision forced", s)
+        else:
+            assert s["epe_delta"] < 1e-3 and s["mean_abs_px"] < 1e-2, ("decision forced, fallback bound", s)
+    # Free run: the contract's bars when no decision came out differently; with flips (each re-draws its pixel from the
+    # noise tape and the refinement spreads it) a bound that still catches a broken kernel: a wrong 3-D stack or refinement
+    # moves EVERY pixel by far more than this.
+    for s in fr_["steps"]:
+        if flips == 0 and raw:
+            assert s["frac_gt_1e-3"] <= bar and s["epe_delta"] < LP.BAR_EPE, ("free run", s)
+        elif flips == 0:
+            assert s["epe_delta"] < 1e-3 and s["mean_abs_px"] < 1e-2, ("free run, diagnostic network", s)
+        else:
+            assert s["epe_delta"] < 5e-3 and s["mean_abs_px"] < 5e-2, ("free run with decision flips, fallback bound", flips, s)
     if flips == 0:
         assert fr_["final"]["epe_delta"] < (LP.BAR_EPE if raw else 1e-3), fr_["final"]
         if raw:
             assert fr_["final"]["frac_gt_1e-3"] <= bar, fr_["final"]
+    else:
+        assert fr_["final"]["epe_delta"] < 1e-3 and fr_["final"]["mean_abs_px"] < 1e-2, ("final with decision flips", flips, fr_["final"])
     return {"teacher_forced": tf, "teacher_forced_split": split, "decision_forced": df, "free_run": fr_, "flips": flips}
 
 

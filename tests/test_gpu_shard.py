@@ -41,23 +41,26 @@ def test_two_process_shards_match_single_process():
 
     dev = torch.device("cuda:0")
     model, x, gt = W.build(dev)
-    acc = M.MetricAccumulator(dev)
-    sums = []
+    scratch = M.MetricAccumulator(dev)
+    sums, rows = [], []
     for lo, hi in ((0, 4), (4, 8)):
-        final, gsum = W.shard_epe(model, x, gt, lo, hi, dev, acc)
+        final, gsum, s8 = W.shard_epe(model, x, gt, lo, hi, dev, scratch)
         sums.append((final.double().sum().item().hex(), gsum))
+        rows.append(s8)
+    # the one global batch of 8 in ONE process: the two ranks' rows are added by the all-reduce before the division, so the
+    # reduced numbers are those of the unsharded batch (reference semantics: mean over the kept images of the GLOBAL batch)
+    acc = M.MetricAccumulator(dev)
+    acc.update_sums(torch.cat(rows))
     single = acc.reduce()
-    assert single == outs[0]["metrics"], (single, outs[0]["metrics"])            # bit for bit (fp64 sums, same order)
-    assert [s[0] for s in sums] == [d["final_hex"] for d in outs]               # the disparities themselves too
+    for n in M.NAMES:
+        assert abs(single[n] - outs[0]["metrics"][n]) <= 1e-13 * max(1.0, abs(single[n])), (n, single, outs[0]["metrics"])
+    assert [s[0] for s in sums] == [d["final_hex"] for d in outs]               # the disparities themselves: bit for bit
     assert [s[1] for s in sums] == [d["gwc_sum"] for d in outs]
     # and the shards carry the bits the same pairs have inside the full batch of 8
     acc8 = M.MetricAccumulator(dev)
-    full, _ = W.shard_epe(model, x, gt, 0, 8, dev, acc8)
+    full, _, _ = W.shard_epe(model, x, gt, 0, 8, dev, acc8)
     assert full[:4].double().sum().item().hex() == sums[0][0] and full[4:].double().sum().item().hex() == sums[1][0]
-    epe8 = acc8.reduce()["EPE"]
-    # mean of 8 == mean of two means of 4, up to the float32 rounding of the per-batch means (the reference's metric
-    # functions return float32 scalars, utils/metrics.py:22-40)
-    assert abs(epe8 - single["EPE"]) < 4e-6 * max(1.0, abs(epe8))
+    assert acc8.reduce() == single                        # same per-image sums, same fp64 additions
 
 
 @pytest.mark.timeout(900)

@@ -91,6 +91,32 @@ def test_hot_path_refuses_cpu(model):
     model.eval()
 
 
+def test_update_glue_refuses_cpu_and_dispatches_autograd_explicitly():
+    """IGEV's update-block glue (update.py:96-102): a CPU tensor raises (no silent F.avg_pool2d / F.interpolate fallback);
+    only a tensor that asks for gradients takes the differentiable torch expression."""
+    from diffuvolume_amd import update as U
+    x = torch.zeros(1, 2, 8, 8)
+    with pytest.raises(DiffuVolumeError):
+        U.pool2x(x)
+    with pytest.raises(DiffuVolumeError):
+        U.interp(x, torch.zeros(1, 2, 16, 16))
+    with pytest.raises(TypeError):
+        U._hip_ok(_cuda_like(x.double()), "probe")
+    xg = x.clone().requires_grad_(True)
+    assert U.pool2x(xg).requires_grad and U.interp(xg, torch.zeros(1, 2, 16, 16)).shape[-1] == 16
+
+
+class _CudaLike(torch.Tensor):
+    """A CPU tensor that claims to be on the GPU (dtype check of `_hip_ok` without a device)."""
+    @property
+    def is_cuda(self):
+        return True
+
+
+def _cuda_like(t):
+    return t.as_subclass(_CudaLike)
+
+
 def test_product_code_never_imports_the_oracle():
     import pathlib
     root = pathlib.Path(__file__).resolve().parents[1] / "diffuvolume_amd"
@@ -133,11 +159,14 @@ def test_per_image_metric_rules():
     vals, keep = M.per_image_values(sums)
     assert keep.tolist() == [True, False, True]
     assert vals[0].tolist() == [0.5, 0.1, 0.4, 0.2, 0.1]
+    # two batches: the first is `sums` above (images 0 and 2 kept: EPE 0.5 and 0 -> 0.25), the second one image of EPE 3
     acc = M.MetricAccumulator("cpu")
-    acc.update({n: torch.tensor(v) for n, v in zip(M.NAMES, (1.0, 0.1, 0.2, 0.3, 0.4))})
-    acc.update({n: torch.tensor(v) for n, v in zip(M.NAMES, (3.0, 0.3, 0.2, 0.3, 0.4))})
+    acc.update_sums(sums)
+    acc.update_sums(torch.tensor([[10.0, 10.0, 30.0, 3.0, 2.0, 3.0, 4.0, 0.0]], dtype=torch.float64))
+    assert acc.table().shape == (2, 6) and acc.table()[0, 5] == 2.0
     out = acc.reduce()
-    assert out["EPE"] == 2.0 and abs(out["D1"] - 0.2) < 1e-7        # AverageMeterDict: mean over batches (fp32 inputs)
+    assert abs(out["EPE"] - (0.5 * (sums[0, 2] / sums[0, 0] + sums[2, 2] / sums[2, 0]) + 3.0) / 2) < 1e-12   # AverageMeterDict: mean over batches
+    assert abs(out["D1"] - ((0.1 + float(sums[2, 3] / sums[2, 0])) / 2 + 0.3) / 2) < 1e-12
 
 
 def test_origin_and_pcw_state_dict_layouts():

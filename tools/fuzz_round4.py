@@ -8,7 +8,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
 import torch.nn.functional as F
 import diffuvolume_amd as dv
-from diffuvolume_amd import submodule as S
+from diffuvolume_amd import _lib, submodule as S
 
 dev = "cuda:0"
 random.seed(97)
@@ -65,7 +65,6 @@ for i in range(n):
         bad += 1
         print("  BAD concat", e, bool(torch.equal(vol, lazy.tensor())))
     # ---- stride-2 convolution: both tilings, the default choice, with and without the filter prologue, a residual
-    import os
     cin, cout = random.choice([1, 4, 8, 12, 32, 64]), random.choice([16, 24, 32, 64, 72, 128])
     bs, ds, hs, ws = random.choice([1, 2, 3]), random.randint(1, 11), random.randint(1, 20), random.choice([1, 2, 7, 31, 32, 33, 63, 64, 65, 120])
     print("S2", i, bs, cin, cout, ds, hs, ws, flush=True)
@@ -79,13 +78,9 @@ for i in range(n):
     ref = torch.relu(ref if res is None else ref + res.double())
     plan = S.Conv3dPlan(ws2, bn, stride=2, act=S.ACT_RELU)
     outs = []
-    for pin in ("big", "small", None):
-        if pin is None:
-            os.environ.pop("DV_S2_TILE", None)
-        else:
-            os.environ["DV_S2_TILE"] = pin
+    for pin in (1, 2, 0):                      # 2 x 4 x 32 tiles, 2 x 2 x 32 tiles, the launcher's own choice
+        _lib.load().dv_conv3d_set_s2_tile(pin)
         outs.append(plan(xs2, in_scale=flt, residual=res).clone())
-    os.environ.pop("DV_S2_TILE", None)
     e = rel(outs[0], ref)
     if not (e < 2e-5 and torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])):
         bad += 1

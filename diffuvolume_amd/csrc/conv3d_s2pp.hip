@@ -134,7 +134,7 @@ __global__ __launch_bounds__(512 + 64 * DV_PP_LOADERS, 1) void conv3d_s2pp_kerne
   const unsigned tq = npairs >> 3, trm = npairs & 7u;
   const unsigned slab_lo = xcd < trm ? xcd * (tq + 1) : trm * (tq + 1) + (xcd - trm) * tq;
   const unsigned slab_n = tq + (xcd < trm ? 1u : 0u);
-  const int my_tiles = bidx < slab_n ? (int)((slab_n - bidx + nbx - 1) / nbx) : 0;  // tiles slab_lo + bidx + k * nbx
+  const int my_tiles = __builtin_amdgcn_readfirstlane(bidx < slab_n ? (int)((slab_n - bidx + nbx - 1) / nbx) : 0);  // pairs slab_lo + bidx + k * nbx
   if (my_tiles == 0) return;
 
   auto tile_at = [&](int k, int h) __attribute__((always_inline)) {               // sub-tile h of this block's k-th pair

@@ -14,6 +14,7 @@ taken per sample.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Callable, Optional, Sequence
 
 import torch
@@ -85,7 +86,50 @@ class IGEVDiffusionLoop:
                                             h * w, _lib.stream_ptr()), "dv_noise_prepare_f64")
         return n01, n01f
 
+    # ---- the GRU iterations of one DDIM step as a hipGraph -------------------------------------------------------
+    # One step launches `iters` x ~30 small kernels (1/8- and 1/16-scale convolutions of 0.06-0.1 ms) from Python through
+    # ctypes: the launch gaps are a measurable part of config 5 (20 steps x 32 iterations per pair).  Within ONE forward
+    # everything a step reads besides its carried state is constant (features, context, geometry volume, stem), so the
+    # first step of a forward is captured and the other steps replay it with (coords1, hidden states, filtered noise)
+    # copied into the graph's static inputs.  `use_graph` (default: DV_IGEV_GRAPH != "0"); the eager loop below is the
+    # same code the capture records.  A new forward (new corr_fn object) re-captures; one graph is kept.
+    use_graph = os.environ.get("DV_IGEV_GRAPH", "1") != "0"
+    _graph = None
+    _graph_warm = False
+
     def _gru_iterations(self, coords0, coords1, flow_init, iters, net_list, inp_list, corr_fn, n01f, stem_2x):
+        ok = (self.use_graph and flow_init is None and coords1.is_cuda and not torch.cuda.is_current_stream_capturing()
+              and all(isinstance(t, torch.Tensor) for t in net_list))
+        if not ok:
+            return self._gru_iterations_eager(coords0, coords1, flow_init, iters, net_list, inp_list, corr_fn, n01f, stem_2x)
+        if not self._graph_warm:           # plans / packed weights are built lazily on the first pass: never inside a capture
+            self._graph_warm = True
+            return self._gru_iterations_eager(coords0, coords1, flow_init, iters, net_list, inp_list, corr_fn, n01f, stem_2x)
+        key = (id(corr_fn), id(inp_list), iters, tuple(coords1.shape), coords0.data_ptr(), id(stem_2x))
+        g = self._graph
+        if g is None or g["key"] != key:
+            self._graph = g = None                                   # drop the previous graph (and its memory pool) first
+            st = {"key": key, "coords1": coords1.clone(), "net": [t.clone() for t in net_list], "n01f": n01f.clone()}
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                st["out"] = self._gru_iterations_eager(coords0, st["coords1"], None, iters, list(st["net"]), inp_list,
+                                                       corr_fn, st["n01f"], stem_2x)
+            st["graph"] = graph
+            st["keep"] = (corr_fn, inp_list, stem_2x, coords0)       # what the recorded launches point at stays alive
+            self._graph = g = st
+        else:
+            g["coords1"].copy_(coords1)
+            for dst, src in zip(g["net"], net_list):
+                dst.copy_(src)
+            g["n01f"].copy_(n01f)
+        g["graph"].replay()
+        flow_up, c1, nl = g["out"]
+        # the graph's outputs live in its pool and are overwritten by the next replay: hand out copies.  (The key's objects
+        # are kept alive by the cached graph, so neither their ids nor their device addresses can be reused by a later forward.)
+        return flow_up.clone(), c1.clone(), [t.clone() for t in nl]
+
+    def _gru_iterations_eager(self, coords0, coords1, flow_init, iters, net_list, inp_list, corr_fn, n01f, stem_2x):
         """igev_stereo_ddim.py:233-261 -- the 2-D update block is the caller's; the lookup is HIP."""
         if flow_init is not None:
             coords1 = coords1 + flow_init

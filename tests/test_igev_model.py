@@ -279,3 +279,24 @@ def test_validate_kitti_sample_runs_the_two_networks_back_to_back():
     valid = (torch.rand(370, 1226, generator=g) > 0.3).float()
     out = validate_kitti_sample(origin, ddim, img1, img2, gt, valid, iters=4)
     assert set(out) == {"epe", "d1"} and 0.0 <= out["d1"] <= 1.0 and out["epe"] >= 0.0 and out["epe"] == out["epe"]
+
+
+@pytest.mark.gpu
+def test_gru_iterations_as_a_hipgraph_give_the_eager_bits():
+    """IGEVDiffusionLoop.use_graph (opt-in, DV_IGEV_GRAPH=1): the GRU iterations of a DDIM step captured once per forward
+    and replayed for the later steps -- same launches, same order, same bits as the eager loop."""
+    from diffuvolume_amd.igev_stereo_ddim import IGEVDiffusionLoop
+    m = build(steps=4, cof=[0.4, 0.1, 0.1, 0.1, 0.3])
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed=3, scale={"update_block.disp_head.conv2.weight": 0.05,
+                                                                      "update_block.disp_head.conv2.bias": 0.0}), strict=True)
+    m = m.to(DEV).eval()
+    img1, img2, flow_full, flow_gt = (t.to(DEV) for t in golden_inputs(11, 64, 160))
+    outs = {}
+    old = IGEVDiffusionLoop.use_graph
+    try:
+        for flag in (False, True, True):
+            IGEVDiffusionLoop.use_graph = flag
+            outs.setdefault(flag, []).append(m(img1, img2, flow_full, flow_gt, iters=5, test_mode=True, noise=NoiseTape(9))[0].clone())
+    finally:
+        IGEVDiffusionLoop.use_graph = old
+    assert torch.equal(outs[False][0], outs[True][0]) and torch.equal(outs[True][0], outs[True][1])

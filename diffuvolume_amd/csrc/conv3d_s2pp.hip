@@ -167,6 +167,9 @@ __global__ __launch_bounds__(512 + 64 * DV_PP_LOADERS, 1) void conv3d_s2pp_kerne
   const unsigned vol_bytes = (unsigned)__builtin_amdgcn_readfirstlane((int)(vol * sizeof(float)));   // <= 2^30 (host)
   const int n_chunk = (a.Cin + KC - 1) / KC;
   const int NCH = (n_chunk + 1) & ~1;                  // chunks run in pairs; a surplus chunk reads zero records
+  // an even number of output-channel blocks: the two tiles of a pair are the two channel blocks of ONE brick -- it is copied
+  // once and both halves of the block read it (64 -> 128: half the copies)
+  const bool share = (a.nco & 1) == 0;
   const int n_steps = my_tiles * NCH;                  // step s = chunk s % NCH of tile s / NCH; brick in buffer s & 1
 
   // Barrier protocol (all five waves, the same count on both paths): P before step 0, then ONE per step, B_s, which the
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(512 + 64 * DV_PP_LOADERS, 1) void conv3d_s2pp_kerne
     };
     auto fetch = [&](float* d0, float* d1) __attribute__((always_inline)) {
       dma_raw(ft0, sob0, fc, d0);
-      dma_raw(ft1, sob1, fc, d1);
+      if (!share) dma_raw(ft1, sob1, fc, d1);
       advance();
     };
     plan(ft0, sob0);
@@ -250,8 +253,8 @@ __global__ __launch_bounds__(512 + 64 * DV_PP_LOADERS, 1) void conv3d_s2pp_kerne
   // =========================== MFMA waves ===========================
   const int sub = wave >> 2, pl = (wave >> 1) & 1, nh = wave & 1;
   const int j = lane & 15, kq = lane >> 4;
-  const float* const raw_a = sub ? raw_a1 : raw_a0;
-  const float* const raw_b = sub ? raw_b1 : raw_b0;
+  const float* const raw_a = (sub && !share) ? raw_a1 : raw_a0;
+  const float* const raw_b = (sub && !share) ? raw_b1 : raw_b0;
 
   // ---- weights: one descriptor over the packed image; lane part of the address = lane * 16 bytes, the (chunk, kd, nt, by)
   // part is scalar ----

@@ -95,6 +95,8 @@ SIGNATURES = {
     "dv_conv2d_1in_f32": (c_int, [P, P, P, P, I, I, I, I, I, I, P]),
     "dv_resize_bilinear_ac_f32": (c_int, [P, P, I, I, I, I, I, P]),
     "dv_avg_pool3s2_f32": (c_int, [P, P, I, I, I, P]),
+    "dv_conv2d_fewin_f32": (c_int, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "dv_instance_norm_act_f32": (c_int, [P, P, I, I, ctypes.c_float, I, P]),
     "dv_geo_filter_lookup_f32": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "dv_masked_metrics_f32": (c_int, [P, P, P, P, I, I, P]),
 }

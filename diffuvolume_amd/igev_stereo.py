@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib
-from .igev_stereo_ddim import IGEVStereo_ddim, context_upsample
+from .igev_stereo_ddim import IGEVStereo_ddim, context_upsample, hip_sequential
 
 _SCHEDULE = ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
              "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
@@ -37,7 +37,7 @@ class IGEVStereo(IGEVStereo_ddim):
             features_left, stem_2x, init_disp, net_list, inp_list, geo_fn = self._front(image1, image2)
             spx_pred = None
             if not test_mode:                            # :187-191 (2-D InstanceNorm heads, once per pair: PyTorch)
-                spx_pred = F.softmax(self.spx(self.spx_2(self.spx_4(features_left[0]), stem_2x)), 1)
+                spx_pred = F.softmax(hip_sequential(self.spx, self.spx_2(hip_sequential(self.spx_4, features_left[0]), stem_2x)), 1)
             b, _, h, w = init_disp.shape
             coords = torch.arange(w, dtype=torch.float32, device=init_disp.device).view(1, 1, 1, w).expand(b, 1, h, w).contiguous()
             unit = torch.ones((b, self.args.max_disp // 4, h, w), dtype=torch.float32, device=init_disp.device)

@@ -24,7 +24,7 @@ from torch import nn
 from . import _lib
 from .acv_ddim import cosine_beta_schedule
 from .head import SinusoidalPositionEmbeddings
-from .submodule import (ACT_LEAKY, ACT_NONE, Conv2dPlan, Conv3dPlan, Deconv2dK4S2Plan, Deconv3dPlan, _dev_f32, build_gwc_volume,
+from .submodule import (ACT_LEAKY, ACT_NONE, ACT_RELU, Conv2dPlan, Conv3dPlan, Deconv2dK4S2Plan, Deconv3dPlan, _dev_f32, build_gwc_volume,
                         feature_gate, softmax_regress)
 
 
@@ -256,6 +256,145 @@ class IGEVDiffusionLoop:
 # Module and parameter names are the reference's, so its checkpoints load unchanged
 # (`corr_stem.conv.weight`, `cost_agg.feature_att_16.feat_att.1.bias`, ...).
 # ---------------------------------------------------------------------------------------------------
+# ---------------------------------------------------------------------------------------------------
+# The once-per-pair 2-D front on the in-tree kernels (round 5): every nn.Conv2d / nn.ConvTranspose2d / BatchNorm2d (eval) /
+# InstanceNorm2d / activation of the feature pyramid, the stems, the context encoder and the spx heads runs through
+# `hip_conv2d` / `instance_norm_act` -- no MIOpen, so a rerun and a shard of a batch give the same bits as the batch
+# (MIOpen may pick another solver on a later call or for another batch size).  Plans are cached per module and rebuilt when
+# a weight is loaded, moved or overwritten in place (key = data pointers + versions).  A tensor that asks for gradients
+# takes the module's own torch expression (explicit autograd dispatch, like submodule.py's builders).
+# ---------------------------------------------------------------------------------------------------
+import weakref
+
+_PLAN_CACHE = weakref.WeakKeyDictionary()
+
+
+def _wants_autograd(x) -> bool:
+    return torch.is_grad_enabled() and x.requires_grad
+
+
+def _bn_tuple(bn):
+    return None if bn is None else (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+
+
+def hip_conv2d(conv: nn.Module, x: torch.Tensor, bn: Optional[nn.BatchNorm2d] = None, act: int = ACT_NONE,
+               residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``act(bn(conv(x)) [+ residual])`` for nn.Conv2d (k 1 / 3 with stride 1 / 2, k 3 / 5 / 7 with <= 4 input channels) and
+    nn.ConvTranspose2d (k 4, stride 2, padding 1) with eval-mode BatchNorm folded, on the HIP kernels."""
+    x = _dev_f32(x, "x")
+    if bn is not None and bn.training:
+        raise _lib.DiffuVolumeError("BatchNorm2d in training mode: the HIP front folds running statistics (model.eval())")
+    tensors = [conv.weight, conv.bias] + (list(_bn_tuple(bn)) if bn is not None else [])
+    key = (act, tuple((t.data_ptr(), t._version) for t in tensors if t is not None))
+    hit = _PLAN_CACHE.get(conv)
+    if hit is None or hit[0] != key:
+        w = conv.weight
+        if isinstance(conv, nn.ConvTranspose2d):
+            if conv.kernel_size != (4, 4) or conv.stride != (2, 2) or conv.padding != (1, 1):
+                raise _lib.DiffuVolumeError("ConvTranspose2d on the HIP front: kernel 4, stride 2, padding 1")
+            plan = Deconv2dK4S2Plan(w, _bn_tuple(bn), bias=conv.bias, act=act, eps=bn.eps if bn is not None else 1e-5)
+        else:
+            k, st = conv.kernel_size[0], conv.stride[0]
+            if (conv.kernel_size != (k, k) or conv.stride != (st, st) or conv.padding != (k // 2, k // 2)
+                    or conv.dilation != (1, 1) or conv.groups != 1 or st not in (1, 2)):
+                raise _lib.DiffuVolumeError(f"Conv2d on the HIP front: square kernel, padding k/2, stride 1 or 2, got {conv}")
+            if w.shape[1] <= 4 and k in (3, 5, 7):
+                plan = _FewInPlan(w, conv.bias, bn, st, act)
+            elif k in (1, 3):
+                plan = Conv2dPlan(w, _bn_tuple(bn), act=act, bias=conv.bias, stride=st, eps=bn.eps if bn is not None else 1e-5)
+            else:
+                raise _lib.DiffuVolumeError(f"Conv2d on the HIP front: unsupported layer {conv}")
+        _PLAN_CACHE[conv] = hit = (key, plan)
+    plan = hit[1]
+    if residual is not None:
+        if isinstance(plan, Conv2dPlan):
+            return plan(x, residual=residual)
+        raise _lib.DiffuVolumeError("residual: 3x3 / 1x1 Conv2d layers only")
+    return plan(x)
+
+
+class _FewInPlan:
+    """nn.Conv2d with <= 4 input channels (the RGB stems, the 7x7 stride-2 stem of the context encoder) [+ eval BatchNorm]
+    [+ activation] on `dv_conv2d_fewin_f32`."""
+
+    def __init__(self, w, bias, bn, stride, act):
+        self.w = w.detach().float().contiguous()
+        self.bias = None if bias is None else bias.detach().float().contiguous()
+        self.cout, self.cin, self.k = w.shape[0], w.shape[1], w.shape[2]
+        self.stride, self.act = stride, act
+        self.scale = self.shift = None
+        if bn is not None:
+            sc = (bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps))
+            self.scale = sc.float().contiguous()
+            self.shift = (bn.bias.detach().double() - bn.running_mean.detach().double() * sc).float().contiguous()
+
+    def __call__(self, x):
+        b, c, h, w = x.shape
+        if c != self.cin:
+            raise RuntimeError(f"expected {self.cin} input channels, got {c}")
+        out = torch.empty((b, self.cout, (h - 1) // self.stride + 1, (w - 1) // self.stride + 1), dtype=torch.float32,
+                          device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().dv_conv2d_fewin_f32(x.data_ptr(), self.w.data_ptr(), _lib.ptr(self.bias),
+                                                       _lib.ptr(self.scale), _lib.ptr(self.shift), out.data_ptr(), b, c, h, w,
+                                                       self.cout, self.k, self.stride, self.act, _lib.stream_ptr()),
+                       "dv_conv2d_fewin_f32")
+        return out
+
+
+def instance_norm_act(x: torch.Tensor, act: int = ACT_NONE, eps: float = 1e-5, inplace: bool = True) -> torch.Tensor:
+    """nn.InstanceNorm2d (affine=False) + activation: `dv_instance_norm_act_f32`, one block per (b, c) plane."""
+    x = _dev_f32(x, "x")
+    b, c, h, w = x.shape
+    out = x if inplace else torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().dv_instance_norm_act_f32(x.data_ptr(), out.data_ptr(), b * c, h * w, float(eps), act,
+                                                        _lib.stream_ptr()), "dv_instance_norm_act_f32")
+    return out
+
+
+_ACT_OF = {nn.ReLU: ACT_RELU, nn.LeakyReLU: ACT_LEAKY}
+
+
+def hip_sequential(seq, x: torch.Tensor) -> torch.Tensor:
+    """An nn.Sequential of the front (stems, spx heads, stub backbone stages, FeatureAtt's gate) with every
+    [conv][BatchNorm2d | InstanceNorm2d][ReLU | ReLU6 | LeakyReLU(0.01)] run fused on the HIP kernels; members that have
+    a HIP forward of their own (BasicConv, BasicConv_IN, ResidualBlock, Conv2x...) are called."""
+    mods = list(seq) if isinstance(seq, (nn.Sequential, list, tuple)) else [seq]
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            j, bn, inorm, act, clamp6 = i + 1, None, None, ACT_NONE, False
+            if j < len(mods) and isinstance(mods[j], nn.BatchNorm2d):
+                bn, j = mods[j], j + 1
+            elif j < len(mods) and isinstance(mods[j], nn.InstanceNorm2d):
+                inorm, j = mods[j], j + 1
+                if inorm.affine or inorm.track_running_stats:
+                    raise _lib.DiffuVolumeError("InstanceNorm2d on the HIP front: affine=False, no running statistics")
+            if j < len(mods) and isinstance(mods[j], (nn.ReLU, nn.ReLU6, nn.LeakyReLU)):
+                a = mods[j]
+                if isinstance(a, nn.LeakyReLU) and abs(a.negative_slope - 0.01) > 1e-12:
+                    raise _lib.DiffuVolumeError("LeakyReLU on the HIP front: negative_slope 0.01")
+                act, clamp6, j = (ACT_RELU if isinstance(a, nn.ReLU6) else _ACT_OF[type(a)]), isinstance(a, nn.ReLU6), j + 1
+            if inorm is not None:
+                x = instance_norm_act(hip_conv2d(m, x), act, inorm.eps)
+            else:
+                x = hip_conv2d(m, x, bn, act)
+            if clamp6:
+                x = x.clamp_(max=6.0)
+            i = j
+        elif isinstance(m, nn.Sequential):
+            x = hip_sequential(m, x)
+            i += 1
+        elif isinstance(m, (nn.Identity, nn.Dropout, nn.Dropout2d)):
+            i += 1
+        else:
+            x = m(x)
+            i += 1
+    return x
+
+
 class BasicConv(nn.Module):
     """core/submodule.py:9-35: conv (bias=False) [+ BatchNorm] [+ LeakyReLU(0.01)].  The 3-D flavours run as
     fused HIP plans (``plan()``); ``forward`` is the 2-D flavour used inside FeatureAtt."""
@@ -282,10 +421,12 @@ class BasicConv(nn.Module):
     def forward(self, x):
         if self.is_3d:
             raise _lib.DiffuVolumeError("3-D BasicConv runs through its HIP plan, not nn.Module.forward")
-        x = self.conv(x)
-        if self.use_bn:
-            x = self.bn(x)
-        return F.leaky_relu(x, 0.01) if self.relu else x
+        if _wants_autograd(x):
+            x = self.conv(x)
+            if self.use_bn:
+                x = self.bn(x)
+            return F.leaky_relu(x, 0.01) if self.relu else x
+        return hip_conv2d(self.conv, x, self.bn if self.use_bn else None, ACT_LEAKY if self.relu else ACT_NONE)
 
 
 class FeatureAtt(nn.Module):
@@ -297,7 +438,7 @@ class FeatureAtt(nn.Module):
                                       nn.Conv2d(feat_chan // 2, cv_chan, 1))
 
     def forward(self, cv, feat, inplace=False):
-        return feature_gate(cv, self.feat_att(feat), inplace=inplace)
+        return feature_gate(cv, hip_sequential(self.feat_att, feat), inplace=inplace)
 
 
 def _seq_plans(seq):
@@ -450,10 +591,15 @@ class BasicConv_IN(nn.Module):
         self.IN = nn.InstanceNorm2d(out_channels)
 
     def forward(self, x):
-        x = self.conv(x)
+        if _wants_autograd(x):
+            x = self.conv(x)
+            if self.use_in:
+                x = self.IN(x)
+            return F.leaky_relu(x, 0.01) if self.relu else x
+        act = ACT_LEAKY if self.relu else ACT_NONE
         if self.use_in:
-            x = self.IN(x)
-        return F.leaky_relu(x, 0.01) if self.relu else x
+            return instance_norm_act(hip_conv2d(self.conv, x), act, self.IN.eps)
+        return hip_conv2d(self.conv, x, None, act)
 
 
 class _Conv2xBase(nn.Module):
@@ -514,11 +660,17 @@ class ResidualBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
 
     def forward(self, x):
-        y = self.relu(self.norm1(self.conv1(x)))
-        y = self.relu(self.norm2(self.conv2(y)))
+        if _wants_autograd(x):
+            y = self.relu(self.norm1(self.conv1(x)))
+            y = self.relu(self.norm2(self.conv2(y)))
+            if self.downsample is not None:
+                x = self.downsample(x)
+            return self.relu(x + y)
+        y = hip_conv2d(self.conv1, x, self.norm1, ACT_RELU)
+        y = hip_conv2d(self.conv2, y, self.norm2, ACT_RELU)
         if self.downsample is not None:
-            x = self.downsample(x)
-        return self.relu(x + y)
+            x = hip_conv2d(self.downsample[0], x, self.downsample[1], ACT_NONE)
+        return torch.relu_(y.add_(x))
 
 
 class MultiBasicEncoder(nn.Module):
@@ -555,17 +707,21 @@ class MultiBasicEncoder(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x, dual_inp=False, num_layers=3):
-        x = self.layer3(self.layer2(self.layer1(self.relu1(self.norm1(self.conv1(x))))))
+        hip = not _wants_autograd(x)
+        head = (lambda f, t: hip_sequential(f, t)) if hip else (lambda f, t: f(t))
+        stem = hip_conv2d(self.conv1, x, self.norm1, ACT_RELU) if hip else self.relu1(self.norm1(self.conv1(x)))
+        x = self.layer3(self.layer2(self.layer1(stem)))
         v = None
         if dual_inp:
             v, x = x, x[:(x.shape[0] // 2)]
         tail = (v,) if dual_inp else ()
-        outs = ([f(x) for f in self.outputs04],)
+        outs = ([head(f, x) for f in self.outputs04],)
         if num_layers >= 2:
             y = self.layer4(x)
-            outs += ([f(y) for f in self.outputs08],)
+            outs += ([head(f, y) for f in self.outputs08],)
         if num_layers >= 3:
-            outs += ([f(self.layer5(y)) for f in self.outputs16],)
+            z = self.layer5(y)
+            outs += ([head(f, z) for f in self.outputs16],)
         return outs + tail
 
 
@@ -591,12 +747,34 @@ class Feature(nn.Module):
         self.deconv8_4 = Conv2x_IN(chans[2] * 2, chans[1], deconv=True, concat=True)
         self.conv4 = BasicConv_IN(chans[1] * 2, chans[1] * 2, kernel_size=3, stride=1, padding=1)
 
+    def _backbone_on_hip(self) -> bool:
+        def plain(m):
+            if isinstance(m, nn.Sequential):
+                return all(plain(c) for c in m)
+            if isinstance(m, nn.Conv2d):
+                k = m.kernel_size[0]
+                return (m.groups == 1 and m.dilation == (1, 1) and m.kernel_size == (k, k) and k in (1, 3)
+                        and m.padding == (k // 2, k // 2) and m.stride[0] in (1, 2) and m.stride[0] == m.stride[1])
+            return isinstance(m, (nn.BatchNorm2d, nn.ReLU, nn.ReLU6, nn.Identity))
+        return all(plain(m) for m in (self.conv_stem, self.bn1, self.act1, self.block0, self.block1, self.block2,
+                                      self.block3, self.block4))
+
     def forward(self, x):
-        x2 = self.block0(self.act1(self.bn1(self.conv_stem(x))))
-        x4 = self.block1(x2)
-        x8 = self.block2(x4)
-        x16 = self.block3(x8)
-        x32 = self.block4(x16)
+        if self._backbone_on_hip() and not _wants_autograd(x):
+            # a backbone made of plain [Conv2d, BatchNorm2d, ReLU / ReLU6] stages (synth.StubMobileNetV2) runs on the
+            # in-tree kernels; anything else (timm's MobileNetV2: depth-wise / squeeze-excite blocks) is the injected
+            # module's own business
+            x2 = hip_sequential(self.block0, hip_sequential([self.conv_stem, self.bn1, self.act1], x))
+            x4 = hip_sequential(self.block1, x2)
+            x8 = hip_sequential(self.block2, x4)
+            x16 = hip_sequential(self.block3, x8)
+            x32 = hip_sequential(self.block4, x16)
+        else:
+            x2 = self.block0(self.act1(self.bn1(self.conv_stem(x))))
+            x4 = self.block1(x2)
+            x8 = self.block2(x4)
+            x16 = self.block3(x8)
+            x32 = self.block4(x16)
         x16 = self.deconv32_16(x32, x16)
         x8 = self.deconv16_8(x16, x8)
         x4 = self.conv4(self.deconv8_4(x8, x4))
@@ -782,18 +960,18 @@ class IGEVStereo_ddim(nn.Module):
         image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
         image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
         features_left, features_right = self.feature(image1), self.feature(image2)
-        stem_2x = self.stem_2(image1)
-        stem_4x = self.stem_4(stem_2x)
-        stem_4y = self.stem_4(self.stem_2(image2))
+        stem_2x = hip_sequential(self.stem_2, image1)
+        stem_4x = hip_sequential(self.stem_4, stem_2x)
+        stem_4y = hip_sequential(self.stem_4, hip_sequential(self.stem_2, image2))
         features_left[0] = torch.cat((features_left[0], stem_4x), 1)
         features_right[0] = torch.cat((features_right[0], stem_4y), 1)
-        match_left = self.desc(self.conv(features_left[0])).float().contiguous()
-        match_right = self.desc(self.conv(features_right[0])).float().contiguous()
+        match_left = hip_conv2d(self.desc, self.conv(features_left[0])).contiguous()
+        match_right = hip_conv2d(self.desc, self.conv(features_right[0])).contiguous()
         geo, init_disp = self.cost_volume(match_left, match_right, features_left)
         cnet_list = self.cnet(image1, num_layers=self.args.n_gru_layers)
         net_list = [torch.tanh(x[0]) for x in cnet_list]
         inp_list = [torch.relu(x[1]) for x in cnet_list]
-        inp_list = [list(conv(i).split(split_size=conv.out_channels // 3, dim=1))
+        inp_list = [list(hip_conv2d(conv, i).split(split_size=conv.out_channels // 3, dim=1))
                     for i, conv in zip(inp_list, self.context_zqr_convs)]
         inp_list = [[t.contiguous() for t in trio] for trio in inp_list]
         from .geometry_ddim import Combined_Geo_Encoding_Volume

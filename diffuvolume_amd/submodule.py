@@ -672,7 +672,7 @@ class Conv2dPairPlan:
     def __call__(self, x, residual=(None, None), mul=(None, None)):
         parts = [_dev_f32(t, "x") for t in (x if isinstance(x, (list, tuple)) else [x])]
         b, _, h, w = parts[0].shape
-        blocks = b * (-(-h // 16)) * (-(-w // 16)) * ((self.c1 + self.c2) // 32)
+        blocks = (-(-h // 16)) * (-(-w // 16)) * ((self.c1 + self.c2) // 32)      # of ONE batch item, see Conv2dPlan
         if self.packed is None or blocks < Conv2dPlan.WINO_MIN_BLOCKS or not 1 <= len(parts) <= 4:
             return (self.single[0](x, residual=residual[0], mul=mul[0]), self.single[1](x, residual=residual[1], mul=mul[1]))
         if sum(t.shape[1] for t in parts) != self.cin or any(t.shape[0] != b or t.shape[2:] != parts[0].shape[2:] for t in parts):
@@ -739,7 +739,10 @@ class Conv2dPlan:
                                                                self.cout, _lib.stream_ptr()), "conv2d wino weight packing")
         self.scale, self.shift = _fold_bn(bn, bias, self.cout, w.device, eps)
 
-    WINO_MIN_BLOCKS = 128
+    # Which kernel runs (Winograd or direct, and the K-split factor of the direct one) decides the ORDER an output is summed
+    # in, so it may only look at ONE batch item: a shard of a batch has to reproduce the batch's bits (round 5: config 5
+    # is sharded over ranks; until then the thresholds counted the whole launch, 128 blocks = 32 per item at batch 4).
+    WINO_MIN_BLOCKS = 32
     WINO_MAX_DILATION = 8       # measured at 1248x384 (tools/ab_wino2d_dil.py): d=2 -27 %, d=4 -19 %, d=8 -11..17 %, d=16 +41..57 % (the gathers spread over too many sectors)
     KSPLIT = True               # K-split the launches that are too small to fill the chip (A/B switch for tools/)
 
@@ -795,7 +798,7 @@ class Conv2dPlan:
         lib = _lib.load()
         d = self.dilation
         if self.wino_packed is not None and d <= self.WINO_MAX_DILATION and \
-                b * d * d * (-(-(-(-h // d)) // 16)) * (-(-(-(-w // d)) // 16)) * (-(-self.cout // 32)) >= self.WINO_MIN_BLOCKS:
+                d * d * (-(-(-(-h // d)) // 16)) * (-(-(-(-w // d)) // 16)) * (-(-self.cout // 32)) >= self.WINO_MIN_BLOCKS:
             import ctypes
             srcs = parts if parts is not None else [x]
             ptrs = (ctypes.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
@@ -812,7 +815,7 @@ class Conv2dPlan:
             return out
         # launches too small to fill the chip (a single IGEV pair at 1/8 and 1/16 resolution): K-split over the input
         # channels, partial tiles in a scratch buffer, fused epilogue in the reduction kernel
-        kslices = lib.dv_conv2d_auto_kslices(b, cin, h, w, self.cout, self.k, self.dilation)
+        kslices = lib.dv_conv2d_auto_kslices(1, cin, h, w, self.cout, self.k, self.dilation)     # (one batch item: see above)
         if kslices > 1 and self.KSPLIT:
             import ctypes
             srcs = parts if parts is not None else [x]

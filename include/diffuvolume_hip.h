@@ -384,6 +384,17 @@ int dv_conv2d_1in_f32(const float* in, const float* w, const float* bias, float*
 int dv_resize_bilinear_ac_f32(const float* in, float* out, int BC, int h, int w, int H, int W, dv_stream_t stream);
 int dv_avg_pool3s2_f32(const float* in, float* out, int BC, int H, int W, dv_stream_t stream);
 
+/* IGEV's once-per-pair 2-D front without MIOpen (csrc/igev_front.hip).
+ * dv_conv2d_fewin_f32: nn.Conv2d(Cin <= 4, Cout, k in {3,5,7}, stride in {1,2}, padding=k/2) [+ bias] [+ folded eval
+ *   BatchNorm: y * ch_scale + ch_shift, both or neither] + activation -- the 7x7 stride-2 stem of the context encoder
+ *   (KITTI15/core/extractor.py:197) and the RGB stems; w [Cout,Cin,k,k]; out [B,Cout,(H-1)/stride+1,(W-1)/stride+1].
+ * dv_instance_norm_act_f32: nn.InstanceNorm2d (affine=False) + activation over BC planes of HW floats
+ *   (core/submodule.py:79-107, igev_stereo_ddim.py:100-117); in-place allowed (out == in). */
+int dv_conv2d_fewin_f32(const float* in, const float* w, const float* bias, const float* ch_scale, const float* ch_shift,
+                        float* out, int B, int Cin, int H, int W, int Cout, int k, int stride, int act,
+                        dv_stream_t stream);
+int dv_instance_norm_act_f32(const float* in, float* out, int BC, int HW, float eps, int act, dv_stream_t stream);
+
 /* ---- IGEV: all-pairs correlation along the epipolar line + its level-1 pooling --------
  * Combined_Geo_Encoding_Volume.corr (KITTI15/core/geometry_ddim.py:72-80: einsum 'aijk,aijh->ajkh') and the
  * avg_pool2d([1,2]) of the pyramid (:28-30), once per stereo pair:

@@ -323,7 +323,7 @@ def test_gru_gate_pair_launch_equals_the_two_convolutions(shape):
     z, rh = pair(parts, residual=(cz, cr), mul=(None, parts[0]))
     z1 = S.Conv2dPlan(w1, None, act=S.ACT_SIGMOID, bias=b1)(parts, residual=cz)
     rh1 = S.Conv2dPlan(w2, None, act=S.ACT_SIGMOID, bias=b2)(parts, residual=cr, mul=parts[0])
-    if b * -(-h // 16) * -(-w // 16) * 4 >= S.Conv2dPlan.WINO_MIN_BLOCKS:        # the single launches are Winograd too
+    if -(-h // 16) * -(-w // 16) * 4 >= S.Conv2dPlan.WINO_MIN_BLOCKS:            # (per batch item) the single launches are Winograd too
         assert torch.equal(z, z1) and torch.equal(rh, rh1)
     else:                                                                        # they ran the direct / K-split kernel
         assert rel_err(z, z1.cpu()) < 1e-5 and rel_err(rh, rh1.cpu()) < 1e-5
@@ -384,3 +384,39 @@ def test_conv2d_source_queue_edge_cases(chans, kernel, monkeypatch):
     # the same through one materialised tensor, and with the sources as views into it (unequal base alignment)
     cat = dev(torch.cat(xs, 1))
     assert torch.equal(plan(cat), out)
+
+
+def test_front_kernels_vs_torch():
+    """csrc/igev_front.hip: the few-input-channel KxK convolution (7x7 stride-2 stem of the context encoder, RGB stems) with
+    folded BatchNorm, and InstanceNorm2d + activation, against float64 torch statements; plus `hip_sequential` on a stem
+    (conv + InstanceNorm + LeakyReLU, conv + InstanceNorm + ReLU) and a transposed-convolution head."""
+    import torch.nn as nn
+    from diffuvolume_amd import _lib
+    from diffuvolume_amd import igev_stereo_ddim as I
+    g = _gen(61, "front")
+    for cin, cout, k, st, h, w in ((3, 64, 7, 2, 37, 50), (3, 32, 3, 2, 33, 47), (1, 16, 5, 1, 9, 20), (4, 70, 7, 1, 18, 17)):
+        conv = nn.Conv2d(cin, cout, k, st, k // 2).to(DEV)
+        bn = nn.BatchNorm2d(cout).to(DEV).eval()
+        with torch.no_grad():
+            bn.running_mean.normal_(0, 0.3); bn.running_var.uniform_(0.5, 1.5); bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+        x = torch.randn(2, cin, h, w, generator=g).to(DEV)
+        with torch.no_grad():
+            ref = torch.relu(bn.double()(conv.double()(x.double())))
+            conv.float(); bn.float()
+            out = I.hip_conv2d(conv, x, bn, S.ACT_RELU)
+        assert out.shape == ref.shape and float((out.double() - ref).abs().max() / ref.abs().max()) < 1e-5, (cin, cout, k, st)
+    x = (torch.randn(3, 5, 21, 34, generator=g) * 3 + 1).to(DEV)
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.instance_norm(x.double()), 0.01)
+    out = I.instance_norm_act(x.clone(), S.ACT_LEAKY)
+    assert float((out.double() - ref).abs().max()) < 1e-5
+    stem = nn.Sequential(I.BasicConv_IN(3, 32, kernel_size=3, stride=2, padding=1), nn.Conv2d(32, 32, 3, 1, 1, bias=False),
+                         nn.InstanceNorm2d(32), nn.ReLU()).to(DEV).eval()
+    head = nn.Sequential(nn.ConvTranspose2d(32, 9, kernel_size=4, stride=2, padding=1)).to(DEV).eval()
+    img = torch.randn(2, 3, 40, 56, generator=g).to(DEV)
+    with torch.no_grad():
+        a = I.hip_sequential(head, I.hip_sequential(stem, img))
+        stem.double(); head.double()
+        ref = head(stem[3](stem[2](stem[1](torch.nn.functional.leaky_relu(stem[0].IN(stem[0].conv(img.double())), 0.01)))))
+    assert a.shape == ref.shape and float((a.double() - ref).abs().max() / ref.abs().max()) < 2e-5
+    with pytest.raises(_lib.DiffuVolumeError):
+        I.hip_conv2d(nn.Conv2d(8, 8, 5, padding=2).to(DEV), torch.zeros(1, 8, 8, 8, device=DEV))

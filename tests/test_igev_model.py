@@ -188,13 +188,12 @@ def test_config5_size_20_steps_32_iterations():
     assert calls["n"] == steps * iters
     assert tuple(both.shape) == (B, 384, 1248) and bool(torch.isfinite(both).all())
     assert float(both.min()) >= 0.0 and float(both.max()) <= 4 * 47 + 1e-3
-    # the HIP kernels are bit-reproducible; the 2-D PyTorch modules around them (backbone, context encoder, stems:
-    # MIOpen) may pick another solver on a later call, so the rerun / shard comparisons allow their re-association
+    # round 5: the 2-D front (feature pyramid on the stub backbone, stems, context encoder, spx heads) runs on the in-tree
+    # kernels too -- no MIOpen solver choice anywhere on the path -- so a rerun and the shards of the batch carry the bits
+    # the batch has (what the N-rank sharding of config 5 rests on)
     again, alone, pair = run(0, B), run(0, 1), run(2, 4)
     for name, x, y in (("rerun", again, both), ("shard [0,1)", alone, both[:1]), ("shard [2,4)", pair, both[2:4])):
-        d = (x - y).abs()
-        print(f"{name}: bit-identical {bool(torch.equal(x, y))}, max |d| {float(d.max()):.3e}")
-        assert float(d.median()) < 1e-4 and float((d > 1e-2).float().mean()) < 1e-2, (name, float(d.max()))
+        assert torch.equal(x, y), (name, float((x - y).abs().max()))
 
 
 # ---- the origin network (KITTI15/core/igev_stereo.py): what evaluate_stereo.py:88 runs first for `flow_pr` ----------

@@ -452,9 +452,11 @@ int launch2d(Conv2dArgs a, hipStream_t s) {
 
 // Slices the library uses for a stride-1 3x3 (dilation <= 4) or 1x1 launch of this size: 1 unless the launch has
 // fewer than 256 blocks of the small-problem tile (4 x 32 pixels x 32 channels) and at least 8 chunks per slice.
-inline int auto_kslices(int B, int Cin, int H, int W, int Cout, int k, int dilation) {
+// The K-split factor decides the order an output is summed in, so it looks at ONE batch item (round 5: a shard of a batch
+// has to reproduce the batch's bits; `B` is kept in the signature and ignored).
+inline int auto_kslices(int /*B*/, int Cin, int H, int W, int Cout, int k, int dilation) {
   if (k != 3 || dilation > 4 || Cout < 32) return 1;
-  const long long blocks = (long long)B * ((H + 3) / 4) * ((W + 31) / 32) * ((Cout + 31) / 32);
+  const long long blocks = (long long)((H + 3) / 4) * ((W + 31) / 32) * ((Cout + 31) / 32);
   if (blocks >= 256) return 1;
   const int nchunk = (Cin + 3) / 4;
   int ks = (int)(1024 / blocks);

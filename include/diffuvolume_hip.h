@@ -213,7 +213,9 @@ int dv_conv2d_cat_f32(const float* const* inputs, const int* channels, int n_inp
  * resolution: KITTI15/core/update.py:33-40 at 48x156 / 24x78 pixels): `kslices` blocks share an output tile, each
  * sums a contiguous range of the input-channel chunks into scratch[kslices][B,Cout,H,W]; a second small kernel adds
  * the slices in a fixed order (deterministic) and applies the same fused epilogue.  kslices must be the value
- * dv_conv2d_auto_kslices returns for this shape (1 = use dv_conv2d_cat_f32); scratch is caller-allocated. */
+ * dv_conv2d_auto_kslices returns for this shape (1 = use dv_conv2d_cat_f32); scratch is caller-allocated.  The factor is a
+ * function of ONE batch item (`B` is ignored since round 5): it fixes the summation order, and a shard of a batch must
+ * reproduce the batch's bits. */
 int dv_conv2d_auto_kslices(int B, int Cin, int H, int W, int Cout, int k, int dilation);
 int dv_conv2d_cat_ksplit_f32(const float* const* inputs, const int* channels, int n_inputs, const float* wpacked,
                              const float* ch_scale, const float* ch_bias, const float* residual, const float* mul,

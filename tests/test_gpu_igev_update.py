@@ -295,7 +295,10 @@ def test_conv2d_ksplit_small_launches(cfg):
     z, hh = torch.rand(1, cout, h, w, generator=g), torch.randn(1, cout, h, w, generator=g)
     lib = _lib.load()
     ks = lib.dv_conv2d_auto_kslices(1, cin, h, w, cout, 3, 1)
-    assert ks > 1 and lib.dv_conv2d_auto_kslices(8, cin, 96, 312, cout, 3, 1) == 1
+    # (the factor is a function of ONE batch item since round 5 -- it fixes the summation order, and a shard of a batch has
+    # to reproduce the batch's bits -- so the batch argument does not move it)
+    assert ks > 1 and lib.dv_conv2d_auto_kslices(8, cin, h, w, cout, 3, 1) == ks
+    assert lib.dv_conv2d_auto_kslices(1, cin, 192, 624, cout, 3, 1) == 1
     fn = {"sigmoid": torch.sigmoid, "tanh": torch.tanh, "relu": torch.relu, "none": lambda t: t}[act]
     y = fn(torch.nn.functional.conv2d(torch.cat(xs, 1), wt, bias, 1, 1) + res) * mul
     y = hh + z * (y - hh)

@@ -53,6 +53,9 @@ struct Wino2dArgs {
   const float* residual2;
   const float* mul2;
   float* out2;
+  // store de-interleaved by 2 (dv_conv2d_wino_s2b_f32): out is [4B, Cout, H/2, W/2], pixel (y, x) of item b goes to item
+  // 4b + 2(y & 1) + (x & 1) at (y >> 1, x >> 1) -- the layout the NEXT layer of a dilation-doubling stack reads densely
+  int s2b;
 };
 
 // DEEP: the low-occupancy variant for launches that do not fill the chip (IGEV's 1/8 and 1/16 scales at batch 1):
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
       }
       continue;
     }
-    const bool plain = fast && plain_act;
+    const bool plain = fast && plain_act && !a.s2b;
     if (plain) {
       if (a.act == DV_ACT_RELU) {
         if (resp) plain_rows(std::true_type{}, std::true_type{});
@@ -419,7 +422,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
             const f32x4 h = *reinterpret_cast<const f32x4*>(a.blend_h + o);
             v = h + z * (v - h);
           }
-          *reinterpret_cast<f32x4*>(outp + o) = v;
+          if (a.s2b) {     // (no residual / mul / blend on this path: the host checks) x = xb + e with xb a multiple of 4
+            const int y = yb + yr;
+            const size_t pl = (size_t)(a.H >> 1) * (a.W >> 1);
+            const size_t ob = (((size_t)b * 4 + 2 * (y & 1)) * coutg + (co - cog0)) * pl + (size_t)(y >> 1) * (a.W >> 1) + (xb >> 1);
+            *reinterpret_cast<f32x2*>(outp + ob) = (f32x2){v[0], v[2]};
+            *reinterpret_cast<f32x2*>(outp + ob + (size_t)coutg * pl) = (f32x2){v[1], v[3]};
+          } else {
+            *reinterpret_cast<f32x4*>(outp + o) = v;
+          }
         } else if (yb + yr < Hs) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
@@ -430,7 +441,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
               u = dv_act(u, a.act);
               if (mulp) u *= mulp[oe];
               if (a.blend_z) u = a.blend_h[oe] + a.blend_z[oe] * (u - a.blend_h[oe]);
-              outp[oe] = u;
+              if (a.s2b) {
+                const int y = yb + yr, x = xb + e;
+                const size_t pl = (size_t)(a.H >> 1) * (a.W >> 1);
+                outp[(((size_t)b * 4 + 2 * (y & 1) + (x & 1)) * coutg + (co - cog0)) * pl + (size_t)(y >> 1) * (a.W >> 1) + (x >> 1)] = u;
+              } else {
+                outp[oe] = u;
+              }
             }
         }
       }
@@ -497,7 +514,8 @@ namespace {
 int wino2d_launch(const float* const* inputs, const int* channels, int n_inputs, const float* wpacked,
                   const float* ch_scale, const float* ch_bias, const float* residual, const float* mul,
                   const float* blend_z, const float* blend_h, float* out, int B, int H, int W, int Cout, int dilation,
-                  int act, int gsplit, const float* residual2, const float* mul2, float* out2, dv_stream_t stream);
+                  int act, int gsplit, const float* residual2, const float* mul2, float* out2, dv_stream_t stream,
+                  int s2b = 0);
 }
 
 extern "C" int dv_conv2d_wino_dil_cat_f32(const float* const* inputs, const int* channels, int n_inputs,
@@ -525,7 +543,8 @@ namespace {
 int wino2d_launch(const float* const* inputs, const int* channels, int n_inputs, const float* wpacked,
                   const float* ch_scale, const float* ch_bias, const float* residual, const float* mul,
                   const float* blend_z, const float* blend_h, float* out, int B, int H, int W, int Cout, int dilation,
-                  int act, int gsplit, const float* residual2, const float* mul2, float* out2, dv_stream_t stream) {
+                  int act, int gsplit, const float* residual2, const float* mul2, float* out2, dv_stream_t stream,
+                  int s2b) {
   DV_REQUIRE_PTR(inputs);
   DV_REQUIRE(dilation >= 1 && dilation <= 16, DV_ERR_UNSUPPORTED);
   DV_REQUIRE_PTR(channels);
@@ -557,6 +576,11 @@ int wino2d_launch(const float* const* inputs, const int* channels, int n_inputs,
               (!mul || dv_aligned16(mul)) && (!blend_z || (dv_aligned16(blend_z) && dv_aligned16(blend_h)));
   a.dil = dilation;
   a.gsplit = gsplit; a.residual2 = residual2; a.mul2 = mul2; a.out2 = out2;
+  a.s2b = s2b;
+  if (s2b) {
+    DV_REQUIRE(dilation == 1 && gsplit == 0 && !residual && !mul && !blend_z && H % 2 == 0 && W % 2 == 0, DV_ERR_UNSUPPORTED);
+    a.fast_ok = (W % 4 == 0) && dv_aligned16(out);
+  }
   a.ntx = cdiv2(cdiv2(W, dilation), w2::TW); a.nty = cdiv2(cdiv2(H, dilation), w2::TH); a.nco = cdiv2(Cout, 32);
   const long long blocks = (long long)B * a.nco * a.nty * a.ntx * dilation * dilation;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return DV_ERR_SHAPE;
@@ -576,4 +600,11 @@ extern "C" int dv_conv2d_wino_cat_f32(const float* const* inputs, const int* cha
                                       dv_stream_t stream) {
   return dv_conv2d_wino_dil_cat_f32(inputs, channels, n_inputs, wpacked, ch_scale, ch_bias, residual, mul, blend_z,
                                     blend_h, out, B, H, W, Cout, 1, act, stream);
+}
+
+extern "C" int dv_conv2d_wino_s2b_f32(const float* const* inputs, const int* channels, int n_inputs, const float* wpacked,
+                                      const float* ch_scale, const float* ch_bias, float* out, int B, int H, int W, int Cout,
+                                      int act, dv_stream_t stream) {
+  return wino2d_launch(inputs, channels, n_inputs, wpacked, ch_scale, ch_bias, nullptr, nullptr, nullptr, nullptr, out, B, H,
+                       W, Cout, 1, act, 0, nullptr, nullptr, nullptr, stream, 1);
 }

@@ -162,3 +162,75 @@ extern "C" int dv_refine_inputs_f32(const float* left, const float* right, const
                      (hipStream_t)stream, a);
   return dv_launch_status();
 }
+
+// ---- space-to-batch for the dilated layers of the refinement network (KITTI12/models/pwcnet_ddim.py:251-306) ----
+// A 3x3 convolution with dilation d is d*d independent dilation-1 convolutions on the sub-images (y % d, x % d).  Run on
+// the image as it lies, every load / store of a sub-image is a 4-byte access at a 4 d-byte stride (d = 8: a wave touches 16
+// cache lines for 64 floats; conv2d_wino at d = 8 issued 0.34 of the matrix pipe, 0.56 at d = 1).  The dilations of
+// refinenet_version3 double from layer to layer (1, 1, 2, 4, 8, 8, 16, 16, 1...), so the stack runs in the sub-image domain
+// instead: one de-interleave by 2 in front of every doubling turns [N, C, h, w] into [4 N, C, h/2, w/2] (sub-image
+// (y & 1, x & 1) of item n becomes item 4 n + 2 (y & 1) + (x & 1)), every dilated layer -- and the residual block around it:
+// 1x1 down-sampling, BatchNorm, Mish and the skip add are pointwise -- becomes a plain dense convolution on that tensor,
+// and one pass puts the pixels back after the last dilated block.
+namespace {
+
+// thread = two neighbouring x of one row: reads 8 bytes, writes one float to each of the two sub-images of that row parity
+// (a wave reads 512 contiguous bytes and writes two runs of 256)
+__global__ void space_to_batch2_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int h, int w,
+                                       size_t pairs) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pairs) return;
+  const int w2 = w >> 1, h2 = h >> 1;
+  const int xp = (int)(i % w2);
+  size_t r = i / w2;
+  const int y = (int)(r % h); r /= h;
+  const int c = (int)(r % C);
+  const size_t n = r / C;
+  const float2 v = *reinterpret_cast<const float2*>(in + (((n * C + c) * h + y) * (size_t)w + 2 * xp));
+  const size_t plane = (size_t)h2 * w2;
+  const size_t o = (((n * 4 + 2 * (y & 1)) * C + c) * plane) + (size_t)(y >> 1) * w2 + xp;
+  out[o] = v.x;
+  out[o + (size_t)C * plane] = v.y;
+}
+
+// the inverse of `levels` de-interleaves at once: thread = one output pixel (b, c, y, x) of [B, C, H, W]
+__global__ void batch_to_space_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int H, int W, int levels,
+                                      size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int x = (int)(i % W);
+  size_t r = i / W;
+  const int y = (int)(r % H); r /= H;
+  const int c = (int)(r % C);
+  size_t n = r / C;
+  for (int l = 0; l < levels; ++l) n = n * 4 + 2 * ((y >> l) & 1) + ((x >> l) & 1);
+  const int hs = H >> levels, ws = W >> levels;
+  out[i] = in[((n * C + c) * hs + (y >> levels)) * (size_t)ws + (x >> levels)];
+}
+
+}  // namespace
+
+extern "C" int dv_space_to_batch2_f32(const float* in, float* out, int N, int C, int h, int w, dv_stream_t stream) {
+  DV_REQUIRE_PTR(in);
+  DV_REQUIRE_PTR(out);
+  DV_REQUIRE(N > 0 && C > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0, DV_ERR_SHAPE);
+  DV_REQUIRE((((uintptr_t)in) & 7u) == 0, DV_ERR_ALIGN);
+  const size_t pairs = (size_t)N * C * h * (w / 2);
+  DV_REQUIRE((pairs + 255) / 256 <= 0x7fffffffull, DV_ERR_SHAPE);
+  hipLaunchKernelGGL(space_to_batch2_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out,
+                     C, h, w, pairs);
+  return dv_launch_status();
+}
+
+extern "C" int dv_batch_to_space_f32(const float* in, float* out, int B, int C, int H, int W, int levels,
+                                     dv_stream_t stream) {
+  DV_REQUIRE_PTR(in);
+  DV_REQUIRE_PTR(out);
+  DV_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && levels >= 1 && levels <= 8, DV_ERR_SHAPE);
+  DV_REQUIRE(H % (1 << levels) == 0 && W % (1 << levels) == 0, DV_ERR_SHAPE);
+  const size_t total = (size_t)B * C * H * W;
+  DV_REQUIRE((total + 255) / 256 <= 0x7fffffffull, DV_ERR_SHAPE);
+  hipLaunchKernelGGL(batch_to_space_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out,
+                     C, H, W, levels, total);
+  return dv_launch_status();
+}

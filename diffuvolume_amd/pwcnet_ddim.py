@@ -336,39 +336,118 @@ class _PairPlan:
         return self.b(self.a(x), residual=x if residual_self else None)
 
 
-def _plan_cb2(seq, act):
-    """convbn 2-D (Conv2d + BatchNorm2d, submodule.py:21-24) -> fused plan."""
+def _plan_cb2(seq, act, dil=None):
+    """convbn 2-D (Conv2d + BatchNorm2d, submodule.py:21-24) -> fused plan.  ``dil``: the dilation LEFT of the layer's own
+    when its input is already de-interleaved into sub-images (`space_to_batch2`, level l: dil = dilation >> l)."""
     conv, bn = seq[0], seq[1]
-    return Conv2dPlan(conv.weight, _bn_of(bn), dilation=conv.dilation[0], act=act, eps=bn.eps, stride=conv.stride[0])
+    return Conv2dPlan(conv.weight, _bn_of(bn), dilation=conv.dilation[0] if dil is None else dil, act=act, eps=bn.eps,
+                      stride=conv.stride[0])
+
+
+def space_to_batch2(x: torch.Tensor) -> torch.Tensor:
+    """[N,C,h,w] -> [4N,C,h/2,w/2]: sub-image (y & 1, x & 1) of item n becomes item 4n + 2(y & 1) + (x & 1) (HIP)."""
+    n, c, h, w = x.shape
+    out = torch.empty((4 * n, c, h // 2, w // 2), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().dv_space_to_batch2_f32(x.data_ptr(), out.data_ptr(), n, c, h, w, _lib.stream_ptr()),
+                   "dv_space_to_batch2_f32")
+    return out
+
+
+def batch_to_space(x: torch.Tensor, levels: int) -> torch.Tensor:
+    """The inverse of ``levels`` applications of `space_to_batch2` at once (HIP)."""
+    n, c, h, w = x.shape
+    b = n >> (2 * levels)
+    out = torch.empty((b, c, h << levels, w << levels), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().dv_batch_to_space_f32(x.data_ptr(), out.data_ptr(), b, c, h << levels, w << levels, levels,
+                                                     _lib.stream_ptr()), "dv_batch_to_space_f32")
+    return out
 
 
 class _Block2dPlan:
     """BasicBlock (submodule.py:192-215): convbn+Mish, convbn, `out += x` (x through the 1x1 downsample when the
     width changes); the add rides in the second convolution's epilogue, no activation after it."""
 
-    def __init__(self, blk: _Block2d):
-        self.conv1 = _plan_cb2(blk.conv1[0], ACT_MISH)
-        self.conv2 = _plan_cb2(blk.conv2, ACT_NONE)
+    def __init__(self, blk: _Block2d, dil=None):
+        self.dilation = blk.conv2[0].dilation[0]
+        self.conv1 = _plan_cb2(blk.conv1[0], ACT_MISH, dil)
+        self.conv2 = _plan_cb2(blk.conv2, ACT_NONE, dil)
         self.down = None if blk.downsample is None else _plan_cb2(blk.downsample, ACT_NONE)
 
-    def __call__(self, x):
+    def __call__(self, x, group=1):
         skip = x if self.down is None else self.down(x)
-        return self.conv2(self.conv1(x), residual=skip)
+        return self.conv2(self.conv1(x, group=group), residual=skip, group=group)
 
 
 class _RefinePlan:
     """refinenet_version3.forward (pwcnet_ddim.py:292-306) on the 2-D implicit-GEMM kernel."""
 
+    # Round 5: the dilated layers run in the sub-image domain (csrc/refine_inputs.hip, `space_to_batch2`): a layer whose
+    # dilation is twice that of the tensor's current de-interleave gets one more de-interleave by 2 in front and is then a
+    # plain dense convolution -- loads and stores of whole cache lines instead of 4-byte accesses at a 4 d-byte stride
+    # (conv2d_wino issued 0.34 of the matrix pipe at d = 8 and 0.56 at d = 1), and the d = 16 block, too far apart for the
+    # dilated Winograd kernel, becomes a Winograd layer as well.  Pointwise members of a block (1x1 down-sampling,
+    # BatchNorm, Mish, the skip add) do not care.  Same arithmetic per output as the dilated kernel (which is the
+    # dilation-1 kernel on a sub-image).  `sub_image_domain = False` keeps every layer on the image as it lies.
+    sub_image_domain = True
+
     def __init__(self, m: RefineNet):
-        self.head = [_plan_cb2(getattr(m, n)[0], ACT_MISH) for n in ("conv1", "conv2", "conv3", "conv4")]
-        self.blocks = [_Block2dPlan(b) for n in ("conv5", "conv6", "conv7") for b in getattr(m, n)]
+        self.mods = [getattr(m, n)[0] for n in ("conv1", "conv2", "conv3", "conv4")]        # convbn of the four head layers
+        self.mods += [b for n in ("conv5", "conv6", "conv7") for b in getattr(m, n)]        # BasicBlocks
+        self.dils = [mod[0].dilation[0] if isinstance(mod, nn.Sequential) else mod.conv2[0].dilation[0] for mod in self.mods]
+        self._cache = {}
         self.conv8 = Conv2dPlan(m.conv8.weight, None, dilation=1, act=ACT_NONE)
+        self.chain_ok = all(d & (d - 1) == 0 for d in self.dils)       # powers of two
+
+    def plan(self, i, dil):
+        """Layer i with `dil` of its dilation left to the kernel (the rest is in the tensor's de-interleave level)."""
+        if (i, dil) not in self._cache:
+            mod = self.mods[i]
+            self._cache[(i, dil)] = (_plan_cb2(mod, ACT_MISH, dil) if isinstance(mod, nn.Sequential) else _Block2dPlan(mod, dil))
+        return self._cache[(i, dil)]
+
+    @staticmethod
+    def max_level(h, w):
+        """How often an h x w plane may be de-interleaved before the 16 x 16 tiles of the Winograd kernel pad the sub-planes
+        by more than 15 % (384 x 1248: three times -- 48 x 156; a fourth gives 24 x 78 planes computed as 32 x 80)."""
+        lvl = 0
+        while h % 2 == 0 and w % 2 == 0:
+            h, w = h // 2, w // 2
+            if (-(-h // 16) * 16) * (-(-w // 16) * 16) > 1.15 * h * w:
+                break
+            lvl += 1
+        return lvl
 
     def __call__(self, x, disp):
-        for p in self.head:
-            x = p(x)
-        for b in self.blocks:
-            x = b(x)
+        h, w = x.shape[-2], x.shape[-1]
+        lmax = self.max_level(h, w)
+        if not (self.sub_image_domain and self.chain_ok and lmax > 0 and max(self.dils) > 1):
+            for i, d in enumerate(self.dils):
+                x = self.plan(i, d)(x)
+            return self.conv8(x, residual=disp)      # disp + conv8(conv7)
+        want = [min(d.bit_length() - 1, lmax) for d in self.dils]      # de-interleave level every layer runs at
+        level = 0                                    # x is de-interleaved `level` times: [B * 4^level, C, h >> level, w >> level]
+        for i, d in enumerate(self.dils):
+            if want[i] < level:                      # back on the image (the dilation-1 tail of the stack)
+                x = batch_to_space(x, level)
+                level = 0
+            while level < want[i]:
+                x = space_to_batch2(x)
+                level += 1
+            plan = self.plan(i, d >> level)
+            # a plain convolution in front of a level step stores its result de-interleaved itself
+            # (`dv_conv2d_wino_s2b_f32`): no separate pass over the tensor
+            nxt = want[i + 1] if i + 1 < len(self.dils) else 0
+            fuse = (nxt == level + 1 and isinstance(plan, Conv2dPlan) and plan.wino_packed is not None and plan.dilation == 1
+                    and x.shape[-2] % 2 == 0 and x.shape[-1] % 2 == 0)
+            if fuse:
+                x = plan(x, group=4 ** level, s2b_out=True)
+                level += 1
+            else:
+                x = plan(x, group=4 ** level) if isinstance(plan, Conv2dPlan) else plan(x, 4 ** level)
+        if level:
+            x = batch_to_space(x, level)
         return self.conv8(x, residual=disp)          # disp + conv8(conv7)
 
 

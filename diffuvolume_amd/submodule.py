@@ -747,10 +747,14 @@ class Conv2dPlan:
     KSPLIT = True               # K-split the launches that are too small to fill the chip (A/B switch for tools/)
 
     def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, mul: Optional[torch.Tensor] = None,
-                 blend: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+                 blend: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, group: int = 1,
+                 s2b_out: bool = False) -> torch.Tensor:
         """act(conv(x)*scale + shift + residual) [* mul] [-> h + z*(. - h) for blend = (z, h)].
         ``x`` may be a list of up to four tensors: the convolution then runs over their channel concatenation
-        without materialising it (stride 1)."""
+        without materialising it (stride 1).  ``group``: how many consecutive batch entries of ``x`` make up ONE sample (the
+        sub-images of a space-to-batch tensor): the per-sample block count that picks the kernel is taken over all of them.
+        ``s2b_out``: store the result de-interleaved by 2, [4B,Cout,H/2,W/2] (`dv_conv2d_wino_s2b_f32`; Winograd layers
+        without residual / mul / blend, even H and W) -- what `pwcnet_ddim.space_to_batch2` would make of it."""
         parts = None
         if isinstance(x, (list, tuple)):
             parts = [_dev_f32(t, "x") for t in x]
@@ -797,8 +801,25 @@ class Conv2dPlan:
         extra = sum(t is not None for t in (residual, mul, bz, bh))
         lib = _lib.load()
         d = self.dilation
+        if s2b_out:
+            if (self.wino_packed is None or d != 1 or self.stride != 1 or extra or h % 2 or w % 2):
+                raise _lib.DiffuVolumeError("s2b_out: a 3x3 dilation-1 stride-1 Winograd layer without residual / mul / "
+                                            "blend on even H and W")
+            import ctypes
+            srcs = parts if parts is not None else [x]
+            ptrs = (ctypes.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
+            chans = (ctypes.c_int * len(srcs))(*[t.shape[1] for t in srcs])
+            out = torch.empty((4 * b, self.cout, h // 2, w // 2), dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device):
+                nb = 4.0 * (sum(t.numel() for t in srcs) + out.numel())
+                timed(f"conv2d_k3d1_co{self.cout}_s2b", 2.0 * out.numel() * cin * 9, nb,
+                      lambda: _lib.check(lib.dv_conv2d_wino_s2b_f32(ptrs, chans, len(srcs), self.wino_packed.data_ptr(),
+                                                                    _lib.ptr(self.scale), _lib.ptr(self.shift), out.data_ptr(),
+                                                                    b, h, w, self.cout, self.act, _lib.stream_ptr()),
+                                         "dv_conv2d_wino_s2b_f32"), issued=2.0 * out.numel() * cin * 9 / WINO_MULT_REDUCTION)
+            return out
         if self.wino_packed is not None and d <= self.WINO_MAX_DILATION and \
-                d * d * (-(-(-(-h // d)) // 16)) * (-(-(-(-w // d)) // 16)) * (-(-self.cout // 32)) >= self.WINO_MIN_BLOCKS:
+                group * d * d * (-(-(-(-h // d)) // 16)) * (-(-(-(-w // d)) // 16)) * (-(-self.cout // 32)) >= self.WINO_MIN_BLOCKS:
             import ctypes
             srcs = parts if parts is not None else [x]
             ptrs = (ctypes.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])

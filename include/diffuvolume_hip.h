@@ -266,6 +266,18 @@ int dv_refine_inputs_f32(const float* left, const float* right, const float* dis
                          const float* du_b, float* out, int B, int C, int H, int W, int maxshift,
                          dv_stream_t stream);
 
+/* Space-to-batch for the dilated layers of refinenet_version3 (KITTI12/models/pwcnet_ddim.py:251-306), csrc/refine_inputs.hip.
+ * dv_space_to_batch2_f32: [N,C,h,w] -> [4N,C,h/2,w/2]; sub-image (y & 1, x & 1) of item n becomes item 4n + 2(y & 1) + (x & 1)
+ *   (h, w even; `in` 8-byte aligned).  A 3x3 convolution with dilation 2d on the input is one with dilation d on the output.
+ * dv_batch_to_space_f32: the inverse of `levels` such steps at once: in [B * 4^levels, C, H >> levels, W >> levels] -> out [B,C,H,W]. */
+int dv_space_to_batch2_f32(const float* in, float* out, int N, int C, int h, int w, dv_stream_t stream);
+/* dv_conv2d_wino_cat_f32 (dilation 1, no residual / mul / blend) with its output stored through dv_space_to_batch2_f32's
+ * mapping: out [4B,Cout,H/2,W/2] (H, W even).  The layer in front of a dilation doubling writes what the next layer reads. */
+int dv_conv2d_wino_s2b_f32(const float* const* inputs, const int* channels, int n_inputs, const float* wpacked,
+                           const float* ch_scale, const float* ch_bias, float* out, int B, int H, int W, int Cout,
+                           int act, dv_stream_t stream);
+int dv_batch_to_space_f32(const float* in, float* out, int B, int C, int H, int W, int levels, dv_stream_t stream);
+
 /* FeatureAtt.forward's broadcast product (KITTI15/core/submodule.py:234-239):
  * out[b,c,d,y,x] = sigmoid(logit[b,c,y,x]) * cv[b,c,d,y,x]; out may alias cv. */
 int dv_feature_gate_f32(const float* cv /*[B,C,D,H,W]*/, const float* logit /*[B,C,H,W]*/, float* out,

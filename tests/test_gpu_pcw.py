@@ -319,3 +319,41 @@ def test_gwcnet_g_is_registered_and_fails_like_the_reference():
     assert str(g["gwcnet_g_forward_error"]) == "RuntimeError"
     with pytest.raises((RuntimeError, KeyError)):
         m(dev(batch["left"]), dev(batch["right"]))
+
+
+def test_refinement_in_the_sub_image_domain():
+    """refinenet_version3 (pwcnet_ddim.py:251-306) with its dilated layers run as dense convolutions on de-interleaved
+    sub-images (`space_to_batch2` / `batch_to_space`, round 5) against the same stack on the image as it lies and against
+    the module's own float64 forward; the two kernels of the round trip against their index definition."""
+    from diffuvolume_amd import pwcnet_ddim as PD
+    g = _gen(321, "refine_sub")
+    x = torch.randn(3, 5, 8, 12, generator=g)
+    s1 = PD.space_to_batch2(dev(x))
+    want = torch.stack([x[n, :, ry::2, rx::2] for n in range(3) for ry in (0, 1) for rx in (0, 1)])
+    assert torch.equal(s1.cpu(), want)
+    assert torch.equal(PD.batch_to_space(PD.space_to_batch2(s1), 2).cpu(), x)
+    m = PD.RefineNet(146)
+    sd = synth_state_dict(m.state_dict(), seed=12)
+    m.load_state_dict(sd)
+    m = m.eval()
+    inp = torch.randn(1, 146, 128, 384, generator=g) * 0.5          # planes that allow three de-interleaves (16 x 48)
+    disp = torch.rand(1, 1, 128, 384, generator=g) * 40
+    with torch.no_grad():
+        ref = m.double()(inp.double(), disp.double())
+    m = m.float().to(DEV)
+    plan = PD._RefinePlan(m)
+    assert plan.chain_ok and plan.max_level(128, 384) == 3 and plan.max_level(384, 1248) == 3
+    try:
+        PD._RefinePlan.sub_image_domain = False
+        plain = plan(dev(inp), dev(disp))
+    finally:
+        PD._RefinePlan.sub_image_domain = True
+    sub = plan(dev(inp), dev(disp))
+    scale = float((ref - disp.double()).abs().max())
+    assert float((plain.cpu().double() - ref).abs().max()) < 2e-5 * max(1.0, scale)
+    assert float((sub.cpu().double() - ref).abs().max()) < 2e-5 * max(1.0, scale)
+    # odd sizes stay (partly) on the image: whatever level the planes allow
+    odd = plan(dev(inp[:, :, :24, :44].contiguous()), dev(disp[:, :, :24, :44].contiguous()))
+    with torch.no_grad():
+        ref_odd = m.double().cpu()(inp[:, :, :24, :44].double(), disp[:, :, :24, :44].double())
+    assert float((odd.cpu().double() - ref_odd).abs().max()) < 2e-5 * max(1.0, scale)

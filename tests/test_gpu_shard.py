@@ -81,3 +81,23 @@ def test_bench_two_ranks_end_to_end_on_one_gpu():
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["dist_backend"] == "gloo" and d["launcher"] == "self"
     assert d["config"]["global_batch"] == 4 and d["scaling"] == "weak" and d["value"] > 0
     assert "roofline" in d and "cpu_baseline" not in d            # CPU baseline is an N = 1 leg
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("workload,extra", [("kitti12", ["--height", "128", "--width", "256"]),
+                                            ("kitti15", ["--height", "128", "--width", "256", "--ddim-steps", "2", "--gru-iters", "3"])])
+def test_bench_two_ranks_other_workloads(workload, extra):
+    """BASELINE configs 4 / 5 through the same N-rank path (`--workload`): two ranks on the one GPU of the test box over gloo,
+    small frames; the contract line names the workload and the all-reduced metric is finite."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["DV_BENCH_OVERSUBSCRIBE"] = "1"
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--workload", workload, "--steps", "1", "--warmup", "1",
+                        "--batch", "1"] + extra, capture_output=True, text=True, timeout=1000, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dist_backend"] == "gloo" and d["launcher"] == "self" and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 2 and d["value"] > 0 and d["unit"] == "pairs/s"
+    assert ("KITTI12" if workload == "kitti12" else "KITTI15") in d["config"]["workload"] and workload[:5].upper() in d["metric"].upper()
+    assert d["epe_px"] == d["epe_px"] and "roofline" in d and d["cpu_baseline"] is None

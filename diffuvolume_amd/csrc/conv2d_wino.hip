@@ -19,6 +19,16 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Timing-only ablations (results are WRONG; tools/build_variant.sh ... -DDV_W2_ABL=n): 1 no raw loads, 2 no LDS commits,
+// 4 no weight DMA, 8 no block barrier, 16 no input transform, 32 no epilogue.
+#ifndef DV_W2_ABL
+#define DV_W2_ABL 0
+#endif
+
+#ifndef DV_W2_PIN
+#define DV_W2_PIN 0
+#endif
+
 namespace w2 {
 constexpr int KC = 8, NKS = 2, NT = 2, TH = 16, TW = 16;
 constexpr int IY = TH + 2, IX = TW + 2;
@@ -61,7 +71,13 @@ struct Wino2dArgs {
 // DEEP: the low-occupancy variant for launches that do not fill the chip (IGEV's 1/8 and 1/16 scales at batch 1):
 // with one block or less per CU nothing hides a chunk's memory latency, so the weight DMA runs two chunks ahead
 // (ring of three LDS images) and the raw loads three (two register sets).
-template <bool DEEP>
+// SRC: how the position in the virtual concatenation advances -- 0: one source (the next plane follows; the feature CNNs,
+// the KITTI12 refinement stack, the motion encoder's single-input layers), 1: several sources whose channel counts
+// (all but the last) are multiples of the 8-channel chunk, so the source queue moves once per chunk (ConvGRU's
+// [h | x...]), 2: any split, the queue is looked at per channel.  The scalar unit issues in the wave's instruction
+// stream: the per-channel selects were ~130 of the 200 scalar instructions of a chunk body, and a wave that spends its
+// issue slots on them cannot keep the matrix pipe fed when its SIMD partner stalls (round 5: one source -7 %).
+template <bool DEEP, int SRC>
 __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
   using namespace w2;
   constexpr int NU = DEEP ? 3 : 2;
@@ -99,18 +115,30 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
   const int n_chunk = (n_in + w2::KC - 1) / w2::KC;
 
   // ---- raw staging plan (as conv3d_wino.hip): buffer loads, zero padding and channel tail from the range check ----
-  unsigned sob[NS];
-  int lro[NS];
+  // A chunk's brick is staged in NP "pieces" (one buffer load + one LDS write per thread each).
+  //  * CC (SRC 0 / 1: the 8 channels of a chunk are 8 consecutive planes of ONE tensor): the chunk is one buffer -- ONE
+  //    descriptor per chunk (base = first plane, records = the planes that exist), the channel is part of the lane's
+  //    offset, and the 8 x 324 positions are dealt to the 256 threads as a whole: 11 pieces.  Positions outside the image
+  //    carry the offset 0x80000000 (out of range: zero), channels past the end fall outside the records (zero, no traffic).
+  //  * otherwise (SRC 2: a chunk may straddle two tensors): per channel a descriptor of one plane and 2 pieces (the second
+  //    27 % full): 16 pieces and ~6 scalar instructions per channel.
+  constexpr bool CC = SRC != 2;
+  constexpr int NP = CC ? (KC * PRAW + 255) / 256 : KC * NS;
+  unsigned sob[CC ? NP : NS];
+  int lro[CC ? NP : NS];
 #pragma unroll
-  for (int i = 0; i < NS; ++i) {
-    const int r = tid + 256 * i;
+  for (int i = 0; i < (CC ? NP : NS); ++i) {
+    const int e = tid + 256 * i;
+    const int cl = CC ? e / PRAW : 0;
+    const int r = e - cl * PRAW;
     const int yy = r / IX, xx = r - yy * IX;
     const int y = ry + dil * (y0 - 1 + yy), x = rx + dil * (x0 - 1 + xx);
-    const bool ok = r < PRAW && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-    sob[i] = ok ? (unsigned)(y * a.W + x) * 4u : 0x80000000u;
-    lro[i] = r < PRAW ? yy * RX + xx : IX;                   // lanes past the brick write a column no patch reads
+    const bool in_brick = CC ? e < KC * PRAW : r < PRAW;
+    const bool ok = in_brick && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+    sob[i] = ok ? (unsigned)cl * (unsigned)plane_bytes + (unsigned)(y * a.W + x) * 4u : 0x80000000u;
+    lro[i] = in_brick ? cl * RAWP + yy * RX + xx : IX;       // lanes past the brick write a column no patch reads
   }
-  typedef float RawSet[KC][NS];
+  typedef float RawSet[NP];
   RawSet vinA, vinB;      // (vinB is only used by the deep variant)
   // Channels are fetched strictly in order (chunk after chunk, also past the end: a channel >= Cin gets a descriptor with
   // zero records and costs no memory traffic), so the position in the virtual concatenation is running scalar state:
@@ -129,30 +157,58 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
   uint64_t nb2 = sgpr64(reinterpret_cast<uint64_t>(a.src[2] + (size_t)b * cw2 * plane));
   uint64_t nb3 = sgpr64(reinterpret_cast<uint64_t>(a.src[3] + (size_t)b * cw3 * plane));
   constexpr int NEVER = 0x7fffffff;                 // an unused source slot: its counter never reaches zero
-  int left = cw0, nl1 = cw1 > 0 ? cw1 : NEVER, nl2 = cw2 > 0 ? cw2 : NEVER, nl3 = cw3 > 0 ? cw3 : NEVER;
+  // (CC: the counters are compared with <= 0 once per chunk and an unused slot holds 0 channels -- once the last source is
+  // used up every later descriptor has zero records)
+  int left = cw0, nl1 = cw1 > 0 ? cw1 : (CC ? 0 : NEVER), nl2 = cw2 > 0 ? cw2 : (CC ? 0 : NEVER),
+      nl3 = cw3 > 0 ? cw3 : (CC ? 0 : NEVER);
   int fc = 0;
-  auto fetch_raw_cl = [&](int /*c0*/, int cl, RawSet& vin) __attribute__((always_inline)) {
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(fb), 0, fc < n_in ? plane_bytes : 0,
-                                                      0x00020000);
-#pragma unroll
-    for (int i = 0; i < NS; ++i)
-      vin[cl][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)sob[i], 0, 0));
-    ++fc;
-    --left;
-    fb += (uint64_t)(unsigned)plane_bytes;
-    const bool sw = left == 0;                      // source exhausted: the queue moves up
+  auto queue_up = [&]() __attribute__((always_inline)) {
+    const bool sw = left <= 0;                      // source exhausted: the queue moves up
     fb = sw ? nb1 : fb;   left = sw ? nl1 : left;
     nb1 = sw ? nb2 : nb1; nl1 = sw ? nl2 : nl1;
     nb2 = sw ? nb3 : nb2; nl2 = sw ? nl3 : nl2;
-    nl3 = sw ? NEVER : nl3;
+    nl3 = sw ? (CC ? 0 : NEVER) : nl3;
   };
-  auto fetch_raw = [&](int c0, RawSet& vin) __attribute__((always_inline)) {
-#pragma unroll
-    for (int cl = 0; cl < KC; ++cl) fetch_raw_cl(c0, cl, vin);
+  // records of a chunk's descriptor = the planes that exist, clamp(left, 0, 8) * plane bytes -- on the scalar unit by hand
+  // (the compiler matches the clamp to v_med3_i32 and then multiplies on the vector ALU too: three vector instructions
+  // alone in the MFMA stream of every chunk)
+  auto records = [&](int l) __attribute__((always_inline)) {
+    int r;
+    asm("s_min_i32 %0, %1, 8\n\ts_max_i32 %0, %0, 0\n\ts_mul_i32 %0, %0, %2" : "=&s"(r) : "s"(l), "s"(plane_bytes) : "scc");
+    return r;
   };
-  auto commit_raw_cl = [&](int cl, float* rb, RawSet& vin) __attribute__((always_inline)) {
+  int nrec = CC ? records(left) : 0;
+  // piece k of the chunk that is next in the stream (pieces are requested strictly in order, chunk after chunk)
+  auto fetch_piece = [&](int k, RawSet& vin) __attribute__((always_inline)) {
+    if (CC) {
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(fb), 0, nrec, 0x00020000);
+      vin[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)sob[k], 0, 0));
+      if (k == NP - 1) {
+        fb += (uint64_t)(unsigned)(KC * plane_bytes);
+        left -= KC;
+        if (SRC == 1) queue_up();
+        nrec = records(left);
+      }
+    } else {
+      const int i = k % NS;
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(fb), 0, fc < n_in ? plane_bytes : 0,
+                                                        0x00020000);
+      vin[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)sob[i], 0, 0));
+      if (i == NS - 1) {
+        ++fc;
+        fb += (uint64_t)(unsigned)plane_bytes;
+        --left;
+        queue_up();
+      }
+    }
+  };
+  auto fetch_raw = [&](RawSet& vin) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < NS; ++i) rb[cl * RAWP + lro[i]] = vin[cl][i];
+    for (int k = 0; k < NP; ++k) fetch_piece(k, vin);
+  };
+  auto commit_piece = [&](int k, float* rb, RawSet& vin) __attribute__((always_inline)) {
+    if (CC) rb[lro[k]] = vin[k];
+    else rb[(k / NS) * RAWP + lro[k % NS]] = vin[k];
   };
   // weights by LDS-DMA, source quad XOR-swizzled with the row (conv3d_wino.hip); 16 pieces of 1 KB, four per wave
   const int dma_lo = (lane >> 2) * 16 + (((lane & 3) ^ ((lane >> 4) & 3)) * 4);
@@ -188,16 +244,16 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
   for (int p4 = 0; p4 < 4; ++p4) b_lo[p4] = (kq * 16 + j) * 16 + ((p4 ^ ((j >> 2) & 3)) * 4);
 
   // ---- prologue.  Chunk k >= 1 travels in register set A (shallow) or set (k & 1 ? B : A) (deep) ----
-  fetch_raw(0, vinA);
+  fetch_raw(vinA);
   dma_u(0, u_s);
 #pragma unroll
-  for (int cl = 0; cl < KC; ++cl) commit_raw_cl(cl, raw_s, vinA);
+  for (int k = 0; k < NP; ++k) commit_piece(k, raw_s, vinA);
   if (DEEP) {
     dma_u(KC, u_s + U_CHUNK);
-    fetch_raw(KC, vinB);
-    fetch_raw(2 * KC, vinA);
+    fetch_raw(vinB);
+    fetch_raw(vinA);
   } else {
-    fetch_raw(KC, vinA);
+    fetch_raw(vinA);
   }
 
   // one chunk.  `vin` holds the raw brick of chunk c0+KC on entry and is refilled for chunk c0+2*KC (deep: c0+3*KC);
@@ -210,10 +266,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
     // past the end is a zero-record descriptor, a weight chunk past the end re-copies the last one into a buffer nobody
     // reads), so the wait count is the same in every chunk and the whole body is one scheduling region -- with a uniform
     // branch per staging step the MFMA stream was cut into 8-instruction basic blocks.
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEEP ? 2 * KC * NS + 4 : KC * NS) : "memory");
-    __syncthreads();
+    if (DV_W2_ABL & 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEEP ? 2 * NP + 4 : NP) : "memory");
+    if (!(DV_W2_ABL & 8)) __syncthreads();
     constexpr bool nxt = true, dma_ok = true, refill = true;
-    const int c_dma = c0 + (DEEP ? 2 : 1) * KC, c_fetch = c0 + (DEEP ? 3 : 2) * KC;
+    const int c_dma = c0 + (DEEP ? 2 : 1) * KC;
     float* rbn = raw_s + (cur ^ 1) * RAW_FLOATS;
     const float* rb = raw_s + cur * RAW_FLOATS + patch_lo;
     f32x2 d[4][2];
@@ -260,7 +317,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
     };
     load_patch(0);
     load_b(0, 0);
-    transform(0);
+    if (DV_W2_ABL & 16) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { vp[0][q][0] = d[q][0]; vp[0][q][1] = d[q][1]; }
+    } else {
+      transform(0);
+    }
 #pragma unroll
     for (int g = 0; g < 4 * NKS; ++g) {
       const int ks = g >> 2, p4 = g & 3;
@@ -269,9 +331,16 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
       // staging in the shadow of the MFMAs: 2 channels of LDS commit per group, then the weight DMA (after the commits:
       // the waits the compiler puts in front of them are vmcnt counts that would otherwise take the DMA along), then
       // 2 channels of refill per group
-      if (g == 4 && dma_ok) dma_u(c_dma, unxt);
-      if (g < 4 && nxt) { commit_raw_cl(2 * g, rbn, vin); commit_raw_cl(2 * g + 1, rbn, vin); }
-      if (g >= 4 && refill) { fetch_raw_cl(c_fetch, 2 * (g - 4), vin); fetch_raw_cl(c_fetch, 2 * (g - 4) + 1, vin); }
+      if (g == 4 && dma_ok && !(DV_W2_ABL & 4)) dma_u(c_dma, unxt);
+      if (g < 4 && nxt && !(DV_W2_ABL & 2)) {
+#pragma unroll
+        for (int k = NP * g / 4; k < NP * (g + 1) / 4; ++k) commit_piece(k, rbn, vin);
+      }
+      if (g >= 4 && refill && !(DV_W2_ABL & 1)) {
+#pragma unroll
+        for (int k = NP * (g - 4) / 4; k < NP * (g - 3) / 4; ++k) fetch_piece(k, vin);
+      }
+      if (DV_W2_PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -279,7 +348,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
           acc[p4 * 4 + e][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(
               vp[ks & 1][p4][e >> 1][e & 1], bq[g & 1][n][e],
               FIRST && ks == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[p4 * 4 + e][n], 0, 0, 0);
-      if (p4 == 1 && ks + 1 < NKS) transform((ks + 1) & 1);
+      if (DV_W2_PIN) __builtin_amdgcn_sched_barrier(0);
+      if (p4 == 1 && ks + 1 < NKS) {
+        if (DV_W2_ABL & 16) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { vp[(ks + 1) & 1][q][0] = d[q][0]; vp[(ks + 1) & 1][q][1] = d[q][1]; }
+        } else {
+          transform((ks + 1) & 1);
+        }
+      }
     }
   };
   if (DEEP) {
@@ -295,11 +372,16 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
 #pragma unroll 1
     for (int c0 = 2 * KC; c0 < n_in; c0 += 2 * KC) pair(c0, std::false_type{});
   } else {
-    chunk(0, 0, u_s, u_s + U_CHUNK, vinA, std::true_type{});
-    int cur = 1;
+    // two chunks per trip: the buffer index is a compile-time constant in each copy of the body, so every LDS address is
+    // a loop-invariant register + an immediate.  With a run-time index the body carried 17 address instructions on the
+    // vector ALU, alone between MFMAs -- the pipe the fp32 MFMAs issue on (round 5: -3 % per launch).
+    auto pair = [&](int c0, auto first_c) __attribute__((always_inline)) {
+      chunk(c0, 0, u_s, u_s + U_CHUNK, vinA, first_c);
+      if (c0 + KC < n_in) chunk(c0 + KC, 1, u_s + U_CHUNK, u_s, vinA, std::false_type{});
+    };
+    pair(0, std::true_type{});
 #pragma unroll 1
-    for (int c0 = KC; c0 < n_in; c0 += KC, cur ^= 1)
-      chunk(c0, cur, u_s + cur * U_CHUNK, u_s + (cur ^ 1) * U_CHUNK, vinA, std::false_type{});
+    for (int c0 = 2 * KC; c0 < n_in; c0 += 2 * KC) pair(c0, std::false_type{});
   }
 
   // the last chunks' surplus weight DMA must have landed before this block's LDS can be given to another one
@@ -308,6 +390,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
   // ---- epilogue: Y = At M A per tile; a lane (cout j, tiles 4kq..4kq+3) holds 4 consecutive x of four rows ----
   const int yb = y0 + 4 * wave, xb = x0 + 4 * kq;
   if (yb >= Hs) return;
+  if ((DV_W2_ABL & 32) && a.Cin > 0) {          // keep the accumulators alive: one store that depends on all of them
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) t += acc[i][n][0] + acc[i][n][1] + acc[i][n][2] + acc[i][n][3];
+    if (t == 123.456f) a.out[0] = t;
+    return;
+  }
   const bool fast = a.fast_ok && dil == 1 && x0 + TW <= a.W && yb + 4 <= a.H;
   const float slope = a.act == DV_ACT_RELU ? 0.f : (a.act == DV_ACT_LEAKY ? 0.01f : 1.f);
   const bool gen = a.act == DV_ACT_MISH || a.act == DV_ACT_SIGMOID || a.act == DV_ACT_TANH;
@@ -585,10 +676,18 @@ int wino2d_launch(const float* const* inputs, const int* channels, int n_inputs,
   const long long blocks = (long long)B * a.nco * a.nty * a.ntx * dilation * dilation;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return DV_ERR_SHAPE;
   // launches that leave most of the chip empty run the deep-prefetch variant
-  if (blocks < 512)
-    hipLaunchKernelGGL(conv2d_wino_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(conv2d_wino_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+#ifndef DV_W2_DEEP_BELOW
+#define DV_W2_DEEP_BELOW 512
+#endif
+  const bool deep = blocks < DV_W2_DEEP_BELOW;
+  int src_mode = n_inputs == 1 ? 0 : 1;
+  for (int i = 0; i + 1 < n_inputs; ++i)
+    if (channels[i] % w2::KC) src_mode = 2;
+  if ((size_t)H * W * sizeof(float) * w2::KC > 0x7fffffffull) src_mode = 2;     // a chunk as ONE buffer: 31-bit lane offsets
+  void (*kern)(Wino2dArgs) =
+      deep ? (src_mode == 0 ? conv2d_wino_kernel<true, 0> : src_mode == 1 ? conv2d_wino_kernel<true, 1> : conv2d_wino_kernel<true, 2>)
+           : (src_mode == 0 ? conv2d_wino_kernel<false, 0> : src_mode == 1 ? conv2d_wino_kernel<false, 1> : conv2d_wino_kernel<false, 2>);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   return dv_launch_status();
 }
 }  // namespace

@@ -6,7 +6,7 @@ On HIP (csrc/conv2d.hip): every 3x3 / 1x1 convolution with its bias and ReLU / s
 arithmetic in the epilogues -- ``convr`` emits ``r*h`` directly, ``convq`` emits ``(1-z)*h + z*tanh(.)`` -- so a
 ConvGRU is three launches; the convolutions read ``[h | x...]`` as a virtual concatenation (``dv_conv2d_cat_f32``).  The 7x7 single-channel ``convd1``, the 3x3 average
 pooling and the bilinear interpolation between the three scales have their own small kernels (csrc/update_glue.hip); PyTorch
-keeps one ``torch.cat`` (the disparity channel appended to the motion features).
+writes the disparity channel into the motion features' 128th channel (the reference's ``torch.cat``).
 """
 from __future__ import annotations
 
@@ -105,19 +105,27 @@ class BasicMotionEncoder(_Planned):
         self.conv = nn.Conv2d(64 + 64, 128 - 1, 3, padding=1)
 
     def _build(self):
-        return {n: _plan(getattr(self, n), ACT_RELU) for n in ("convc1", "convc2", "convd2", "conv")}
+        p = {n: _plan(getattr(self, n), ACT_RELU) for n in ("convc1", "convc2", "convd2")}
+        # `conv` with one all-zero output channel appended: the launch writes the [B,128,h,w] tensor the reference builds with
+        # torch.cat([out, disp]) (update.py:94) and channel 127 (relu(0) = 0) is then overwritten with the disparity.  gru04
+        # reads ONE 128-channel source instead of 127 + 1, so every source of its virtual concatenation is a whole number of
+        # the kernel's 8-channel chunks (csrc/conv2d_wino.hip, SRC = 1: the source queue moves once per chunk).
+        w, b = self.conv.weight, self.conv.bias
+        p["conv"] = Conv2dPlan(torch.cat([w, w.new_zeros((1,) + tuple(w.shape[1:]))]), None, dilation=1, act=ACT_RELU,
+                               bias=torch.cat([b, b.new_zeros(1)]))
+        return p
 
     def forward(self, disp, corr):
-        return torch.cat(self.features(disp, corr), dim=1)           # update.py:94 (the reference's return value)
+        return self.features(disp, corr)                # update.py:94 (the reference's return value)
 
     def features(self, disp, corr):
-        """The two halves of the motion features, (conv output [B,127,h,w], disp [B,1,h,w]): the update block hands
-        them to gru04 as two sources of its virtual concatenation instead of materialising torch.cat per iteration."""
+        """The motion features [B,128,h,w] = [conv output (127) | disp (1)], update.py:88-94."""
         p = self.plans()
         cor = p["convc2"](p["convc1"](corr))
         disp_ = p["convd2"](self._convd1(disp))
         out = p["conv"]([cor, disp_])                   # virtual concatenation: torch.cat([cor, disp_]) is never materialised
-        return out, disp.contiguous()
+        out[:, -1:].copy_(disp)
+        return out
 
     def _convd1(self, disp):
         """relu(convd1(disp)): the 7x7 single-input-channel convolution on its own VALU kernel (MIOpen picks a naive
@@ -212,11 +220,11 @@ class BasicMultiUpdateBlock(_Planned):
                 else:
                     net[1] = self.gru08(net[1], *(inp[1]), pool2x(net[0]))
             if iter04:
-                mf, dsp = self.encoder.features(disp, corr)          # [h | mf | disp | interp]: four sources, no cat
+                mf = self.encoder.features(disp, corr)               # [h | mf+disp | interp]: three sources, no cat
                 if self.args.n_gru_layers > 1:
-                    net[0] = self.gru04(net[0], *(inp[0]), mf, dsp, interp(net[1], net[0]))
+                    net[0] = self.gru04(net[0], *(inp[0]), mf, interp(net[1], net[0]))
                 else:
-                    net[0] = self.gru04(net[0], *(inp[0]), mf, dsp)
+                    net[0] = self.gru04(net[0], *(inp[0]), mf)
             if not update:
                 return net
             delta_disp = self.disp_head(net[0])

@@ -33,7 +33,15 @@ __device__ __forceinline__ void sample_pos(float x, int n, int& i0, float& w0, f
 // reads from there by its own index (the sample positions keep the reference's float arithmetic, so an index may sit
 // one off the integer expectation: the window has room for that).  24 gathers per channel instead of 54: the gathers
 // are what the kernel costs when neighbouring pixels disagree about d (each lane then pulls its own cache line).
+//
+// Round 5: WHICH lanes read WHAT.  The window copy used to be 24 gathers per lane at the lane's own dlo: where neighbouring
+// pixels disagree about d (random-init weights, occlusion borders) every lane of a load instruction pulls a different plane,
+// i.e. up to 64 cache lines per instruction -- the kernel ran at 145 us per call at batch 4 for ~230 MB of traffic.  Now a
+// wave walks the planes k = min(dlo) .. max(dlo) + 23 of its 64 pixels TOGETHER: every lane loads plane k at its own pixel
+// (one 256-byte segment per instruction, whatever the disparities are) and keeps the value if k lies in its window.  Smooth
+// disparity: 24-26 coalesced loads per channel; the worst case is the D planes of the channel once.
 constexpr int GEO_WIN = 24;
+constexpr int GEO_BATCH = 8;        // planes requested per round trip
 
 template <int R>
 __global__ __launch_bounds__(256) void geo_lookup_kernel(const float* __restrict__ geo,
@@ -49,8 +57,9 @@ __global__ __launch_bounds__(256) void geo_lookup_kernel(const float* __restrict
   __shared__ float gwin[GEO_WIN * 256];
   __shared__ float nwin[GEO_WIN * 256];
   const int tid = threadIdx.x;
-  const size_t n = (size_t)blockIdx.x * blockDim.x + tid;
-  if (n >= npix) return;
+  const size_t n0 = (size_t)blockIdx.x * blockDim.x + tid;
+  const bool live = n0 < npix;
+  const size_t n = live ? n0 : npix - 1;                // (a lane past the end shadows the last pixel and stores nothing)
   const size_t hw = (size_t)h * w;
   const size_t b = n / hw, p = n - b * hw;
   const float d = disp[n], cx = coords[n];
@@ -62,8 +71,45 @@ __global__ __launch_bounds__(256) void geo_lookup_kernel(const float* __restrict
   const int dlo = 2 * (int)floorf(d * 0.5f) - 10;
   float* gw = gwin + tid;                               // entry k at gw[k * 256]
   float* nw = nwin + tid;
+  if ((D & 3) == 0) {
+    // the pixel's noise window is 96 contiguous bytes of its own row: seven aligned 16-byte loads (dlo is even, the row
+    // starts on a 16-byte boundary when D % 4 == 0) instead of 24 single floats -- every one of them a different cache
+    // line per lane
+    const int base = dlo & ~3;
 #pragma unroll
-  for (int k = 0; k < GEO_WIN; ++k) nw[k * 256] = (unsigned)(dlo + k) < (unsigned)D ? nrow[dlo + k] : 0.f;
+    for (int k = 0; k < GEO_WIN; ++k) { nw[k * 256] = 0.f; if ((unsigned)(dlo + k) >= (unsigned)D) gw[k * 256] = 0.f; }
+    float4 nq[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const int kk = base + 4 * q;
+      nq[q] = (unsigned)kk < (unsigned)D ? *reinterpret_cast<const float4*>(nrow + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const float e4[4] = {nq[q].x, nq[q].y, nq[q].z, nq[q].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int slot = base + 4 * q + e - dlo;          // (base - dlo is 0 or -2)
+        if ((unsigned)slot < (unsigned)GEO_WIN) nw[slot * 256] = e4[e];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < GEO_WIN; ++k) {
+      const bool in = (unsigned)(dlo + k) < (unsigned)D;
+      nw[k * 256] = in ? nrow[dlo + k] : 0.f;
+      if (!in) gw[k * 256] = 0.f;                       // slots outside [0, D) stay zero for every channel
+    }
+  }
+  // the planes this wave walks: the union of its lanes' windows inside [0, D)
+  int klo = dlo, khi = dlo;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    klo = min(klo, __shfl_xor(klo, off));
+    khi = max(khi, __shfl_xor(khi, off));
+  }
+  klo = __builtin_amdgcn_readfirstlane(max(klo, 0));
+  khi = __builtin_amdgcn_readfirstlane(min(khi + GEO_WIN, D));     // exclusive
   // sample positions of the 2 x 9 taps (the reference's arithmetic), as window slots
   int s0[T], s1[T];
   float a0[T], b0[T], a1[T], b1[T];
@@ -92,15 +138,23 @@ __global__ __launch_bounds__(256) void geo_lookup_kernel(const float* __restrict
   float* o1 = o + (size_t)(C * T + T) * hw;
   for (int c = 0; c < C; ++c) {
     const float* gc = g + (size_t)c * D * hw;
+    for (int k0 = klo; k0 < khi; k0 += GEO_BATCH) {
+      float gv[GEO_BATCH];
 #pragma unroll
-    for (int k = 0; k < GEO_WIN; ++k) gw[k * 256] = (unsigned)(dlo + k) < (unsigned)D ? gc[(size_t)(dlo + k) * hw] : 0.f;
+      for (int i = 0; i < GEO_BATCH; ++i) gv[i] = gc[(size_t)min(k0 + i, khi - 1) * hw];      // every lane, plane k0 + i
+#pragma unroll
+      for (int i = 0; i < GEO_BATCH; ++i) {
+        const int slot = min(k0 + i, khi - 1) - dlo;
+        if ((unsigned)slot < (unsigned)GEO_WIN) gw[slot * 256] = gv[i];
+      }
+    }
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const float v0 = gw[s0[t] * 256] * n00[t], v1 = gw[(s0[t] + 1) * 256] * n01[t];
-      o[(size_t)(c * T + t) * hw] = v0 * a0[t] + v1 * b0[t];
+      if (live) o[(size_t)(c * T + t) * hw] = v0 * a0[t] + v1 * b0[t];
       const float u0 = ((gw[s1[t] * 256] + gw[(s1[t] + 1) * 256]) * 0.5f) * n10[t];
       const float u1 = ((gw[(s1[t] + 2) * 256] + gw[(s1[t] + 3) * 256]) * 0.5f) * n11[t];
-      o1[(size_t)(c * T + t) * hw] = u0 * a1[t] + u1 * b1[t];
+      if (live) o1[(size_t)(c * T + t) * hw] = u0 * a1[t] + u1 * b1[t];
     }
   }
   // the two correlation rows (one gather pair per tap each)
@@ -110,11 +164,11 @@ __global__ __launch_bounds__(256) void geo_lookup_kernel(const float* __restrict
     sample_pos(cx - d + (float)(t - R), W2, i0, w0, w1);
     const float* cr = corr0 + n * W2;
     const float c0 = (i0 >= 0 && i0 < W2) ? cr[i0] : 0.f, c1 = (i0 + 1 >= 0 && i0 + 1 < W2) ? cr[i0 + 1] : 0.f;
-    o[(size_t)(C * T + t) * hw] = c0 * w0 + c1 * w1;
+    if (live) o[(size_t)(C * T + t) * hw] = c0 * w0 + c1 * w1;
     sample_pos(cx / 2.0f - d / 2.0f + (float)(t - R), W2b, i0, w0, w1);
     const float* cr1 = corr1 + n * W2b;
     const float e0 = (i0 >= 0 && i0 < W2b) ? cr1[i0] : 0.f, e1 = (i0 + 1 >= 0 && i0 + 1 < W2b) ? cr1[i0 + 1] : 0.f;
-    o1[(size_t)(C * T + t) * hw] = e0 * w0 + e1 * w1;
+    if (live) o1[(size_t)(C * T + t) * hw] = e0 * w0 + e1 * w1;
   }
 }
 

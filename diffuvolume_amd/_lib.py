@@ -101,6 +101,9 @@ SIGNATURES = {
     "dv_conv2d_fewin_f32": (c_int, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "dv_instance_norm_act_f32": (c_int, [P, P, I, I, ctypes.c_float, I, P]),
     "dv_geo_filter_lookup_f32": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "dv_geo_lookup_conv1x1_packed_floats": (c_size_t, [I]),
+    "dv_geo_lookup_conv1x1_pack_weights_f32": (c_int, [P, P, I, P]),
+    "dv_geo_filter_lookup_conv1x1_f32": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "dv_masked_metrics_f32": (c_int, [P, P, P, P, I, I, P]),
 }
 

@@ -43,19 +43,76 @@ __device__ __forceinline__ void sample_pos(float x, int n, int& i0, float& w0, f
 constexpr int GEO_WIN = 24;
 constexpr int GEO_BATCH = 8;        // planes requested per round trip
 
-template <int R>
+// FUSED: the lookup together with the 1x1 convolution that is its only consumer in IGEV's update block
+// (BasicMotionEncoder.convc1 + bias + ReLU, KITTI15/core/update.py:79,:89: 2*(C*9+9) = 162 -> 64 channels), so that the
+// [B,162,h,w] tensor -- 78 MB written and read back per GRU iteration at batch 4 -- never exists; out is [B,64,h,w].
+// The lookup produces, per geometry channel c, 18 values per pixel (9 taps x 2 levels; the two correlation rows make a
+// ninth group): a wave parks them in a private LDS tile vals[k][pixel] and multiplies on the matrix cores,
+//     acc[cout][pixel] += Wk[group][k][cout] * vals[k][pixel]       (v_mfma_f32_16x16x4_f32: M = cout, N = pixel, K = k)
+// with K padded from 18 to 20 per group (two zero rows).  The A fragments (weights, 20 floats per lane and group) come
+// straight from global memory (41 KB, L2-resident), requested before the group's gathers; the 64 x 64 accumulator tile of the
+// wave stays in registers until the ReLU.  The sum over the 162 lookup channels has a fixed order: bit-reproducible.
+typedef float geo_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int GEO_KG = 20;          // k rows per group (18 used)
+constexpr int GEO_VS = 80;          // row stride of the value tile: the four k rows of a B fragment fall on disjoint banks
+constexpr int GEO_NF = 64;          // output channels of the fused convolution
+
+template <int R, bool FUSED>
 __global__ __launch_bounds__(256) void geo_lookup_kernel(const float* __restrict__ geo,
                                                          const float* __restrict__ corr0,
                                                          const float* __restrict__ corr1,
                                                          const float* __restrict__ disp,
                                                          const float* __restrict__ coords,
                                                          const float* __restrict__ noisy,
+                                                         const float* __restrict__ wk,      // FUSED: [C+1][20][64]
+                                                         const float* __restrict__ bias,    // FUSED: [64] or null
                                                          float* __restrict__ out, int C, int D, int h, int w,
-                                                         int W2, size_t npix) {
+                                                         int W2, size_t npix, int act) {
   constexpr int T = 2 * R + 1;
   static_assert(R == 4, "window sized for radius 4");
   __shared__ float gwin[GEO_WIN * 256];
   __shared__ float nwin[GEO_WIN * 256];
+  __shared__ float vals_s[FUSED ? 4 * GEO_KG * GEO_VS : 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mj = lane & 15, kq = lane >> 4;
+  float* const vals = vals_s + (FUSED ? wave * GEO_KG * GEO_VS : 0);
+  geo_f32x4 acc[FUSED ? 4 : 1][FUSED ? 4 : 1];
+  if (FUSED) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (geo_f32x4){0.f, 0.f, 0.f, 0.f};
+    vals[18 * GEO_VS + lane] = 0.f;                     // the two padding rows of K
+    vals[19 * GEO_VS + lane] = 0.f;
+  }
+  // FUSED: the A fragments of group g (this lane: cout 16*mt + mj, k rows 4*ks + kq), and the group's MFMAs
+  float wa[FUSED ? 20 : 1];
+  auto fetch_w = [&](int g) __attribute__((always_inline)) {
+    if (FUSED) {
+      const float* wg = wk + (size_t)g * (GEO_KG * GEO_NF) + kq * GEO_NF + mj;
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) wa[ks * 4 + mt] = wg[ks * 4 * GEO_NF + mt * 16];
+    }
+  };
+  auto multiply = [&]() __attribute__((always_inline)) {
+    if (FUSED) {
+      __builtin_amdgcn_wave_barrier();                  // (LDS requests of a wave are served in order: writes, then reads)
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) {
+        float bv[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bv[nt] = vals[(ks * 4 + kq) * GEO_VS + nt * 16 + mj];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ks * 4 + mt], bv[nt], acc[mt][nt], 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  };
   const int tid = threadIdx.x;
   const size_t n0 = (size_t)blockIdx.x * blockDim.x + tid;
   const bool live = n0 < npix;
@@ -67,7 +124,7 @@ __global__ __launch_bounds__(256) void geo_lookup_kernel(const float* __restrict
   const float* g = geo + b * C * D * hw + p;            // + (c*D + dd) * hw
   const int W2b = W2 / 2, D1 = D / 2;
   const int nch = 2 * (C * T + T);
-  float* o = out + b * nch * hw + p;                    // + channel * hw
+  float* o = out + (FUSED ? 0 : b * nch * hw + p);      // + channel * hw
   const int dlo = 2 * (int)floorf(d * 0.5f) - 10;
   float* gw = gwin + tid;                               // entry k at gw[k * 256]
   float* nw = nwin + tid;
@@ -135,8 +192,9 @@ __global__ __launch_bounds__(256) void geo_lookup_kernel(const float* __restrict
     n10[t] = ok10[t] ? (nw[s1[t] * 256] + nw[(s1[t] + 1) * 256]) * 0.5f : 0.f;      // (an odd D has one entry past the pairs)
     n11[t] = ok11[t] ? (nw[(s1[t] + 2) * 256] + nw[(s1[t] + 3) * 256]) * 0.5f : 0.f;
   }
-  float* o1 = o + (size_t)(C * T + T) * hw;
+  float* o1 = o + (FUSED ? 0 : (size_t)(C * T + T) * hw);
   for (int c = 0; c < C; ++c) {
+    fetch_w(c);
     const float* gc = g + (size_t)c * D * hw;
     for (int k0 = klo; k0 < khi; k0 += GEO_BATCH) {
       float gv[GEO_BATCH];
@@ -151,12 +209,16 @@ __global__ __launch_bounds__(256) void geo_lookup_kernel(const float* __restrict
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const float v0 = gw[s0[t] * 256] * n00[t], v1 = gw[(s0[t] + 1) * 256] * n01[t];
-      if (live) o[(size_t)(c * T + t) * hw] = v0 * a0[t] + v1 * b0[t];
+      if (FUSED) vals[t * GEO_VS + lane] = v0 * a0[t] + v1 * b0[t];
+      else if (live) o[(size_t)(c * T + t) * hw] = v0 * a0[t] + v1 * b0[t];
       const float u0 = ((gw[s1[t] * 256] + gw[(s1[t] + 1) * 256]) * 0.5f) * n10[t];
       const float u1 = ((gw[(s1[t] + 2) * 256] + gw[(s1[t] + 3) * 256]) * 0.5f) * n11[t];
-      if (live) o1[(size_t)(c * T + t) * hw] = u0 * a1[t] + u1 * b1[t];
+      if (FUSED) vals[(T + t) * GEO_VS + lane] = u0 * a1[t] + u1 * b1[t];
+      else if (live) o1[(size_t)(c * T + t) * hw] = u0 * a1[t] + u1 * b1[t];
     }
+    multiply();
   }
+  fetch_w(C);
   // the two correlation rows (one gather pair per tap each)
 #pragma unroll
   for (int t = 0; t < T; ++t) {
@@ -164,11 +226,31 @@ __global__ __launch_bounds__(256) void geo_lookup_kernel(const float* __restrict
     sample_pos(cx - d + (float)(t - R), W2, i0, w0, w1);
     const float* cr = corr0 + n * W2;
     const float c0 = (i0 >= 0 && i0 < W2) ? cr[i0] : 0.f, c1 = (i0 + 1 >= 0 && i0 + 1 < W2) ? cr[i0 + 1] : 0.f;
-    if (live) o[(size_t)(C * T + t) * hw] = c0 * w0 + c1 * w1;
+    if (FUSED) vals[t * GEO_VS + lane] = c0 * w0 + c1 * w1;
+    else if (live) o[(size_t)(C * T + t) * hw] = c0 * w0 + c1 * w1;
     sample_pos(cx / 2.0f - d / 2.0f + (float)(t - R), W2b, i0, w0, w1);
     const float* cr1 = corr1 + n * W2b;
     const float e0 = (i0 >= 0 && i0 < W2b) ? cr1[i0] : 0.f, e1 = (i0 + 1 >= 0 && i0 + 1 < W2b) ? cr1[i0 + 1] : 0.f;
-    if (live) o1[(size_t)(C * T + t) * hw] = e0 * w0 + e1 * w1;
+    if (FUSED) vals[(T + t) * GEO_VS + lane] = e0 * w0 + e1 * w1;
+    else if (live) o1[(size_t)(C * T + t) * hw] = e0 * w0 + e1 * w1;
+  }
+  if (FUSED) {
+    multiply();
+    // acc[mt][nt][i]: cout 16*mt + 4*kq + i of pixel 16*nt + mj of this wave -- 16 consecutive pixels per (cout, store)
+    const size_t nw0 = (size_t)blockIdx.x * blockDim.x + wave * 64;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const size_t np = nw0 + nt * 16 + mj;
+      if (np >= npix) continue;
+      const size_t bb = np / hw, pp = np - bb * hw;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int co = mt * 16 + kq * 4 + i;
+          out[(bb * GEO_NF + co) * hw + pp] = dv_act(acc[mt][nt][i] + (bias ? bias[co] : 0.f), act);
+        }
+    }
   }
 }
 
@@ -188,7 +270,56 @@ extern "C" int dv_geo_filter_lookup_f32(const float* geo, const float* corr0, co
   DV_REQUIRE(B > 0 && C > 0 && D > 3 && h > 0 && w > 0 && W2 > 3, DV_ERR_SHAPE);
   DV_REQUIRE(radius == 4, DV_ERR_UNSUPPORTED);   // corr_radius of every IGEV config (evaluate_stereo.py)
   const size_t npix = (size_t)B * h * w;
-  hipLaunchKernelGGL(geo_lookup_kernel<4>, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     geo, corr0, corr1, disp, coords, noisy, out, C, D, h, w, W2, npix);
+  hipLaunchKernelGGL((geo_lookup_kernel<4, false>), dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     geo, corr0, corr1, disp, coords, noisy, nullptr, nullptr, out, C, D, h, w, W2, npix, DV_ACT_NONE);
+  return dv_launch_status();
+}
+
+extern "C" size_t dv_geo_lookup_conv1x1_packed_floats(int C) { return C > 0 ? (size_t)(C + 1) * GEO_KG * GEO_NF : 0; }
+
+namespace {
+// w [64][2*(C*9+9)] (the nn.Conv2d 1x1 weight) -> wk [C+1][20][64]: group c < C holds lookup channels c*9 + t (k = t) and
+// half + c*9 + t (k = 9 + t), group C the correlation rows C*9 + t and half + C*9 + t; k = 18, 19 are zero
+__global__ void pack_geo_conv_weights_kernel(const float* __restrict__ w, float* __restrict__ wk, int C) {
+  const int total = (C + 1) * GEO_KG * GEO_NF;
+  const int half = C * 9 + 9, nch = 2 * half;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int co = i % GEO_NF, k = (i / GEO_NF) % GEO_KG, g = i / (GEO_NF * GEO_KG);
+    float v = 0.f;
+    if (k < 18) {
+      const int ch = (k < 9 ? 0 : half) + g * 9 + (k < 9 ? k : k - 9);
+      v = w[(size_t)co * nch + ch];
+    }
+    wk[i] = v;
+  }
+}
+}  // namespace
+
+extern "C" int dv_geo_lookup_conv1x1_pack_weights_f32(const float* w, float* wpacked, int C, dv_stream_t stream) {
+  DV_REQUIRE_PTR(w);
+  DV_REQUIRE_PTR(wpacked);
+  DV_REQUIRE(C > 0, DV_ERR_SHAPE);
+  hipLaunchKernelGGL(pack_geo_conv_weights_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, w, wpacked, C);
+  return dv_launch_status();
+}
+
+extern "C" int dv_geo_filter_lookup_conv1x1_f32(const float* geo, const float* corr0, const float* corr1, const float* disp,
+                                                const float* coords, const float* noisy, const float* wpacked,
+                                                const float* bias, float* out, int B, int C, int D, int h, int w, int W2,
+                                                int radius, int Cout, int act, dv_stream_t stream) {
+  DV_REQUIRE_PTR(geo);
+  DV_REQUIRE_PTR(corr0);
+  DV_REQUIRE_PTR(corr1);
+  DV_REQUIRE_PTR(disp);
+  DV_REQUIRE_PTR(coords);
+  DV_REQUIRE_PTR(noisy);
+  DV_REQUIRE_PTR(wpacked);
+  DV_REQUIRE_PTR(out);
+  DV_REQUIRE(B > 0 && C > 0 && D > 3 && h > 0 && w > 0 && W2 > 3, DV_ERR_SHAPE);
+  DV_REQUIRE(radius == 4 && Cout == GEO_NF, DV_ERR_UNSUPPORTED);      // BasicMotionEncoder.convc1 of every IGEV config
+  DV_REQUIRE(act >= DV_ACT_NONE && act <= DV_ACT_TANH, DV_ERR_UNSUPPORTED);
+  const size_t npix = (size_t)B * h * w;
+  hipLaunchKernelGGL((geo_lookup_kernel<4, true>), dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     geo, corr0, corr1, disp, coords, noisy, wpacked, bias, out, C, D, h, w, W2, npix, act);
   return dv_launch_status();
 }

@@ -143,7 +143,8 @@ class IGEVDiffusionLoop:
         skip_mask = isinstance(self.update_block, BasicMultiUpdateBlock)
         for itr in range(iters):
             flow = coords1 - coords0
-            corr = corr_fn(flow, coords1, n01f)
+            # this build's update block takes the lookup as a request and runs it fused with its first convolution
+            corr = corr_fn.request(flow, coords1, n01f) if (skip_mask and hasattr(corr_fn, "request")) else corr_fn(flow, coords1, n01f)
             if self.n_gru_layers == 3 and self.slow_fast_gru:
                 net_list = self.update_block(net_list, inp_list, iter32=True, iter16=False, iter08=False, update=False)
             if self.n_gru_layers >= 2 and self.slow_fast_gru:

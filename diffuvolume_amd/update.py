@@ -106,6 +106,13 @@ class BasicMotionEncoder(_Planned):
 
     def _build(self):
         p = {n: _plan(getattr(self, n), ACT_RELU) for n in ("convc1", "convc2", "convd2")}
+        # convc1 fused into the geometry lookup that feeds it (csrc/geo_lookup.hip), when the caller hands over the lookup
+        # as a request instead of a tensor (this build's IGEVDiffusionLoop does)
+        p["convc1_lookup"] = None
+        if self.convc1.out_channels == 64 and self.convc1.in_channels == 162:
+            from .geometry_ddim import pack_lookup_conv1x1
+            p["convc1_lookup"] = (pack_lookup_conv1x1(self.convc1.weight, 8),
+                                  None if self.convc1.bias is None else self.convc1.bias.detach().float().contiguous())
         # `conv` with one all-zero output channel appended: the launch writes the [B,128,h,w] tensor the reference builds with
         # torch.cat([out, disp]) (update.py:94) and channel 127 (relu(0) = 0) is then overwritten with the disparity.  gru04
         # reads ONE 128-channel source instead of 127 + 1, so every source of its virtual concatenation is a whole number of
@@ -121,7 +128,15 @@ class BasicMotionEncoder(_Planned):
     def features(self, disp, corr):
         """The motion features [B,128,h,w] = [conv output (127) | disp (1)], update.py:88-94."""
         p = self.plans()
-        cor = p["convc2"](p["convc1"](corr))
+        from .geometry_ddim import GeoLookupRequest
+        if isinstance(corr, GeoLookupRequest):
+            if p["convc1_lookup"] is not None and corr.volume.channel == 8:
+                cor = corr.conv1x1(p["convc1_lookup"][0], p["convc1_lookup"][1], ACT_RELU)
+            else:
+                cor = p["convc1"](corr.materialize())
+        else:
+            cor = p["convc1"](corr)
+        cor = p["convc2"](cor)
         disp_ = p["convd2"](self._convd1(disp))
         out = p["conv"]([cor, disp_])                   # virtual concatenation: torch.cat([cor, disp_]) is never materialised
         out[:, -1:].copy_(disp)

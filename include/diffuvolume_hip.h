@@ -427,6 +427,16 @@ int dv_allpairs_corr_f32(const float* fmap1, const float* fmap2, float* corr0, f
 int dv_geo_filter_lookup_f32(const float* geo, const float* corr0, const float* corr1,
                              const float* disp, const float* coords, const float* noisy, float* out,
                              int B, int C, int D, int h, int w, int W2, int radius, dv_stream_t stream);
+/* The same lookup FUSED with the 1x1 convolution that consumes it in IGEV's update block (BasicMotionEncoder.convc1 +
+ * bias + ReLU, KITTI15/core/update.py:79,:89): out[b, co, y, x] = act(bias[co] + sum_ch w[co, ch] * lookup[b, ch, y, x]),
+ * out [B,64,h,w]; the [B,2*(C*9+9),h,w] lookup tensor is never written.  `wpacked` = dv_geo_lookup_conv1x1_pack_weights_f32 of
+ * the nn.Conv2d weight [64, 2*(C*9+9)] (dv_geo_lookup_conv1x1_packed_floats(C) floats); Cout must be 64, radius 4. */
+size_t dv_geo_lookup_conv1x1_packed_floats(int C);
+int dv_geo_lookup_conv1x1_pack_weights_f32(const float* w, float* wpacked, int C, dv_stream_t stream);
+int dv_geo_filter_lookup_conv1x1_f32(const float* geo, const float* corr0, const float* corr1, const float* disp,
+                                     const float* coords, const float* noisy, const float* wpacked, const float* bias,
+                                     float* out, int B, int C, int D, int h, int w, int W2, int radius, int Cout, int act,
+                                     dv_stream_t stream);
 
 /* ---- metrics (SceneFlow/utils/metrics.py:22-65) -------------------------------
  * Per-image sums over pixels with mask!=0: sums[b] = { n_mask, n_gt_pos, sum|gt-est|,

@@ -569,6 +569,37 @@ def test_igev_geo_filter_lookup_window_edges(d):
     torch.testing.assert_close(out.cpu(), ref, atol=3e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("cfg", [(2, 12, 78, 48), (1, 6, 40, 13), (3, 5, 21, 48)])
+def test_igev_geo_lookup_fused_with_its_1x1_convolution(cfg):
+    """`dv_geo_filter_lookup_conv1x1_f32` (csrc/geo_lookup.hip): lookup + BasicMotionEncoder.convc1 + bias + ReLU in one
+    kernel (KITTI15/core/update.py:79,:89) against the 1x1 convolution of the materialised lookup in float64; ragged pixel
+    counts (partial waves / blocks), disparities beyond both ends, an odd D; the result of an item does not depend on its batch."""
+    from diffuvolume_amd.geometry_ddim import Combined_Geo_Encoding_Volume, pack_lookup_conv1x1
+    from diffuvolume_amd.submodule import ACT_RELU
+    b, h, w, d = cfg
+    c = 8
+    gen = _gen(65, f"fusedlookup{cfg}")
+    geo = torch.randn(b, c, d, h, w, generator=gen)
+    f1, f2 = torch.randn(b, 16, h, w, generator=gen), torch.randn(b, 16, h, w, generator=gen)
+    disp = torch.rand(b, 1, h, w, generator=gen) * (d + 12) - 6
+    coords = torch.arange(w, dtype=torch.float32).view(1, 1, 1, w).expand(b, 1, h, w).contiguous()
+    noisy = torch.rand(b, d, h, w, generator=gen)
+    wt = torch.randn(64, 162, 1, 1, generator=gen) * 0.1
+    bias = torch.randn(64, generator=gen) * 0.1
+    fn = Combined_Geo_Encoding_Volume(dev(f1), dev(f2), dev(geo))
+    look = fn(dev(disp), dev(coords), dev(noisy))
+    ref = torch.relu(torch.nn.functional.conv2d(look.double(), dev(wt).double(), dev(bias).double()))
+    wp = pack_lookup_conv1x1(dev(wt), c)
+    out = fn.request(dev(disp), dev(coords), dev(noisy)).conv1x1(wp, dev(bias), ACT_RELU)
+    assert out.shape == ref.shape
+    assert float((out.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(fn.request(dev(disp), dev(coords), dev(noisy)).materialize(), look)
+    if b > 1:                                              # shard invariance: item 1 alone
+        fn1 = Combined_Geo_Encoding_Volume(dev(f1[1:2]), dev(f2[1:2]), dev(geo[1:2]))
+        one = fn1.lookup_conv1x1(dev(disp[1:2]), dev(coords[1:2]), dev(noisy[1:2].contiguous()), wp, dev(bias), ACT_RELU)
+        assert torch.equal(one, out[1:2])
+
+
 @pytest.mark.parametrize("shape", [(1, 24, 3, 78, 78), (2, 96, 2, 40, 40), (1, 7, 2, 17, 33), (1, 130, 1, 16, 21),
                                    (1, 4, 1, 5, 2)])
 def test_igev_allpairs_corr_oracle(shape):

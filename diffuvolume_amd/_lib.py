@@ -80,6 +80,9 @@ SIGNATURES = {
     "dv_conv2d_wino_dil_cat_f32": (c_int, [P, P, I, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "dv_refine_inputs_f32": (c_int, [P, P, P, P, P, P, I, I, I, I, I, P]),
     "dv_space_to_batch2_f32": (c_int, [P, P, I, I, I, I, P]),
+    "dv_conv2d_wino_auto_kslices": (c_int, [I, I, I, I, I]),
+    "dv_conv2d_wino_cat_ksplit_f32": (c_int, [P, P, I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "dv_conv2d_wino_cat_pair_ksplit_f32": (c_int, [P, P, I, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "dv_conv2d_wino_s2b_f32": (c_int, [P, P, I, P, P, P, P, I, I, I, I, I, P]),
     "dv_batch_to_space_f32": (c_int, [P, P, I, I, I, I, I, P]),
     "dv_softmax_regress_f32": (c_int, [P, P, I, I, I, I, P]),

@@ -66,6 +66,11 @@ struct Wino2dArgs {
   // store de-interleaved by 2 (dv_conv2d_wino_s2b_f32): out is [4B, Cout, H/2, W/2], pixel (y, x) of item b goes to item
   // 4b + 2(y & 1) + (x & 1) at (y >> 1, x >> 1) -- the layout the NEXT layer of a dilation-doubling stack reads densely
   int s2b;
+  // K-split (KS kernels): `kslices` blocks share an output tile, each sums a contiguous range of the 8-channel chunks and
+  // stores its raw tile sums to scratch[slice][B, Cout, H, W]; wino2d_ksplit_epilogue_kernel adds the slices in slice order
+  // (deterministic) and applies the epilogue.  For the launches that leave most of the chip empty (IGEV's 1/16 scale).
+  int kslices;
+  float* scratch;
 };
 
 // DEEP: the low-occupancy variant for launches that do not fill the chip (IGEV's 1/8 and 1/16 scales at batch 1):
@@ -77,7 +82,7 @@ struct Wino2dArgs {
 // [h | x...]), 2: any split, the queue is looked at per channel.  The scalar unit issues in the wave's instruction
 // stream: the per-channel selects were ~130 of the 200 scalar instructions of a chunk body, and a wave that spends its
 // issue slots on them cannot keep the matrix pipe fed when its SIMD partner stalls (round 5: one source -7 %).
-template <bool DEEP, int SRC>
+template <bool DEEP, int SRC, bool KS = false>
 __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
   using namespace w2;
   constexpr int NU = DEEP ? 3 : 2;
@@ -95,6 +100,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
   // stores is the dilation-1 kernel.  The sub-image index is the fastest tile index, so the d*d blocks that share
   // the same cache lines of input and output run side by side on one XCD.
   unsigned t = dv_xcd_remap(blockIdx.x, gridDim.x);
+  const int slice = KS ? __builtin_amdgcn_readfirstlane((int)(t % (unsigned)a.kslices)) : 0;
+  if (KS) t /= (unsigned)a.kslices;
   const int dil = a.dil;
   const int sg = t % (unsigned)(dil * dil); t /= (unsigned)(dil * dil);
   const int ry = sg / dil, rx = sg - ry * dil;
@@ -113,6 +120,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
   const int plane_bytes = (int)(plane * sizeof(float));      // < 2^31 (checked by the host)
   const int n_in = a.Cin;
   const int n_chunk = (n_in + w2::KC - 1) / w2::KC;
+  // this block's chunks: all of them, or its slice of a K-split launch
+  const int cbeg = KS ? (n_chunk * slice) / a.kslices : 0;
+  const int cend = KS ? (n_chunk * (slice + 1)) / a.kslices : n_chunk;
+  const int c_first = cbeg * w2::KC, c_lim = KS ? min(n_in, cend * w2::KC) : n_in;
 
   // ---- raw staging plan (as conv3d_wino.hip): buffer loads, zero padding and channel tail from the range check ----
   // A chunk's brick is staged in NP "pieces" (one buffer load + one LDS write per thread each).
@@ -177,6 +188,14 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
     asm("s_min_i32 %0, %1, 8\n\ts_max_i32 %0, %0, 0\n\ts_mul_i32 %0, %0, %2" : "=&s"(r) : "s"(l), "s"(plane_bytes) : "scc");
     return r;
   };
+  if (KS) {                                         // walk the source queue to this slice's first chunk
+    for (int i = 0; i < cbeg * (CC ? 1 : KC); ++i) {
+      fb += (uint64_t)(unsigned)((CC ? KC : 1) * plane_bytes);
+      left -= CC ? KC : 1;
+      if (!CC) ++fc;
+      if (SRC != 0) queue_up();
+    }
+  }
   int nrec = CC ? records(left) : 0;
   // piece k of the chunk that is next in the stream (pieces are requested strictly in order, chunk after chunk)
   auto fetch_piece = [&](int k, RawSet& vin) __attribute__((always_inline)) {
@@ -215,9 +234,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
   const int dma_voff = dma_lo * 4;                 // the lane part of a piece's source address: constant
   // the weight chunks are copied strictly in order too: a running scalar pointer to this wave's first piece of the next
   // chunk (a chunk past the end re-copies the last one: the staging in `chunk` is issued unconditionally)
-  uint64_t ud = sgpr64(reinterpret_cast<uint64_t>(a.wpk + (size_t)tc * U_CHUNK + wave * 256));
+  uint64_t ud = sgpr64(reinterpret_cast<uint64_t>(a.wpk + ((size_t)cbeg * a.nco + tc) * U_CHUNK + wave * 256));
   const uint64_t ud_step = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane(a.nco * U_CHUNK * (int)sizeof(float));
-  int ud_left = n_chunk - 1;                         // advances left before the pointer stays on the last chunk
+  int ud_left = cend - cbeg - 1;                         // advances left before the pointer stays on the last chunk
   auto dma_u = [&](int /*c0*/, float* ub) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -365,23 +384,23 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
     auto pair = [&](int c0, auto first_c) __attribute__((always_inline)) {
       const int iu1 = iu == 2 ? 0 : iu + 1, iu2 = iu1 == 2 ? 0 : iu1 + 1;
       chunk(c0, 0, u_s + iu * U_CHUNK, u_s + iu2 * U_CHUNK, vinB, first_c);
-      if (c0 + KC < n_in) chunk(c0 + KC, 1, u_s + iu1 * U_CHUNK, u_s + iu * U_CHUNK, vinA, std::false_type{});
+      if (c0 + KC < c_lim) chunk(c0 + KC, 1, u_s + iu1 * U_CHUNK, u_s + iu * U_CHUNK, vinA, std::false_type{});
       iu = iu2;
     };
-    pair(0, std::true_type{});
+    pair(c_first, std::true_type{});
 #pragma unroll 1
-    for (int c0 = 2 * KC; c0 < n_in; c0 += 2 * KC) pair(c0, std::false_type{});
+    for (int c0 = c_first + 2 * KC; c0 < c_lim; c0 += 2 * KC) pair(c0, std::false_type{});
   } else {
     // two chunks per trip: the buffer index is a compile-time constant in each copy of the body, so every LDS address is
     // a loop-invariant register + an immediate.  With a run-time index the body carried 17 address instructions on the
     // vector ALU, alone between MFMAs -- the pipe the fp32 MFMAs issue on (round 5: -3 % per launch).
     auto pair = [&](int c0, auto first_c) __attribute__((always_inline)) {
       chunk(c0, 0, u_s, u_s + U_CHUNK, vinA, first_c);
-      if (c0 + KC < n_in) chunk(c0 + KC, 1, u_s + U_CHUNK, u_s, vinA, std::false_type{});
+      if (c0 + KC < c_lim) chunk(c0 + KC, 1, u_s + U_CHUNK, u_s, vinA, std::false_type{});
     };
-    pair(0, std::true_type{});
+    pair(c_first, std::true_type{});
 #pragma unroll 1
-    for (int c0 = 2 * KC; c0 < n_in; c0 += 2 * KC) pair(c0, std::false_type{});
+    for (int c0 = c_first + 2 * KC; c0 < c_lim; c0 += 2 * KC) pair(c0, std::false_type{});
   }
 
   // the last chunks' surplus weight DMA must have landed before this block's LDS can be given to another one
@@ -436,6 +455,23 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
       yq2[h][0][1] = s0[1] - s0[2] - s0[3];
       yq2[h][1][0] = s1[0] + s1[1] + s1[2];
       yq2[h][1][1] = s1[1] - s1[2] - s1[3];
+    }
+    if (KS) {      // raw tile sums of this slice -> scratch[slice][B, Cout, H, W]; the epilogue runs in the reduction kernel
+      float* sp = a.scratch + (size_t)slice * ((size_t)a.B * a.Cout * plane) +
+                  (((size_t)b * a.Cout + co) * a.H + (ry + dil * yb)) * a.W + (rx + dil * xb);
+#pragma unroll
+      for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int yr = 2 * tr + r;
+          const float y4[4] = {yq2[0][r][0][tr], yq2[0][r][1][tr], yq2[1][r][0][tr], yq2[1][r][1][tr]};
+          if (yb + yr < Hs) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (xb + e < Ws) sp[(size_t)(dil * yr) * a.W + (size_t)(dil * e)] = y4[e];
+          }
+        }
+      continue;
     }
     auto plain_rows = [&](auto relu_c, auto res_c) __attribute__((always_inline)) {
       constexpr bool RELU = decltype(relu_c)::value, RES = decltype(res_c)::value;
@@ -581,6 +617,44 @@ __global__ void pack_wino2d_weights_kernel(const float* __restrict__ w, float* _
 
 inline int cdiv2(int a, int b) { return (a + b - 1) / b; }
 
+// sum of the K-split slices (fixed order) + the epilogue of conv2d_wino_kernel, incl. the two-group form of the gate pair
+__global__ __launch_bounds__(256) void wino2d_ksplit_epilogue_kernel(Wino2dArgs a, size_t total, size_t oplane) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  float v = a.scratch[i];
+  for (int sl = 1; sl < a.kslices; ++sl) v += a.scratch[(size_t)sl * total + i];
+  const size_t pc = i / oplane, p = i - pc * oplane;
+  const int co = (int)(pc % (size_t)a.Cout);
+  const size_t b = pc / (size_t)a.Cout;
+  const bool g2 = a.gsplit > 0 && co >= a.gsplit;
+  const int cog0 = g2 ? a.gsplit : 0, coutg = g2 ? a.Cout - a.gsplit : (a.gsplit > 0 ? a.gsplit : a.Cout);
+  const size_t o = (b * coutg + (co - cog0)) * oplane + p;
+  const float* resp = g2 ? a.residual2 : a.residual;
+  const float* mulp = g2 ? a.mul2 : a.mul;
+  v = fmaf(v, a.ch_scale ? a.ch_scale[co] : 1.f, a.ch_bias ? a.ch_bias[co] : 0.f);
+  if (resp) v += resp[o];
+  v = dv_act(v, a.act);
+  if (mulp) v *= mulp[o];
+  if (a.blend_z) v = a.blend_h[o] + a.blend_z[o] * (v - a.blend_h[o]);
+  (g2 ? a.out2 : a.out)[o] = v;
+}
+
+// (measured at batch 4, 24 x 78: gate pair 104 us unsplit, 92 / 86 / 86 us at up to 4 / 2 / 3 slices; candidate 75 -> 58 / 58 / 48)
+// Slices of a Winograd launch: 1 unless ONE batch item has at most 96 blocks (the rule may only look at one item: a shard of
+// a batch has to sum in the batch's order) and the slices keep >= 8 chunks each.  At batch 4 this is IGEV's 1/16 scale
+// (80 / 40 blocks per item): 320 blocks of 32 chunks leave 3/4 of the SIMDs with one wave or none.
+inline int wino2d_kslices(int Cin, int H, int W, int Cout, int dilation) {
+  const long long blocks = (long long)cdiv2(cdiv2(H, dilation), w2::TH) * cdiv2(cdiv2(W, dilation), w2::TW) * cdiv2(Cout, 32) *
+                           dilation * dilation;
+  const int nchunk = cdiv2(Cin, w2::KC);
+  if (blocks > 96 || nchunk < 16) return 1;
+#ifndef DV_W2_KS_MAX
+#define DV_W2_KS_MAX 3
+#endif
+  const int ks = nchunk / 8;
+  return ks > DV_W2_KS_MAX ? DV_W2_KS_MAX : ks;
+}
+
 }  // namespace
 
 extern "C" size_t dv_conv2d_wino_packed_floats(int Cin, int Cout) {
@@ -606,7 +680,37 @@ int wino2d_launch(const float* const* inputs, const int* channels, int n_inputs,
                   const float* ch_scale, const float* ch_bias, const float* residual, const float* mul,
                   const float* blend_z, const float* blend_h, float* out, int B, int H, int W, int Cout, int dilation,
                   int act, int gsplit, const float* residual2, const float* mul2, float* out2, dv_stream_t stream,
-                  int s2b = 0);
+                  int s2b = 0, float* scratch = nullptr, int kslices = 1);
+}
+
+extern "C" int dv_conv2d_wino_auto_kslices(int Cin, int H, int W, int Cout, int dilation) {
+  if (Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || dilation < 1) return 1;
+  return wino2d_kslices(Cin, H, W, Cout, dilation);
+}
+
+// The K-split forms of dv_conv2d_wino_dil_cat_f32 / dv_conv2d_wino_cat_pair_f32: `kslices` must be
+// dv_conv2d_wino_auto_kslices(Cin, H, W, Cout [both convolutions], dilation) > 1, scratch holds kslices * B * Cout * H * W floats.
+extern "C" int dv_conv2d_wino_cat_ksplit_f32(const float* const* inputs, const int* channels, int n_inputs,
+                                             const float* wpacked, const float* ch_scale, const float* ch_bias,
+                                             const float* residual, const float* mul, const float* blend_z,
+                                             const float* blend_h, float* out, float* scratch, int kslices, int B, int H,
+                                             int W, int Cout, int dilation, int act, dv_stream_t stream) {
+  DV_REQUIRE_PTR(scratch);
+  return wino2d_launch(inputs, channels, n_inputs, wpacked, ch_scale, ch_bias, residual, mul, blend_z, blend_h, out, B, H,
+                       W, Cout, dilation, act, 0, nullptr, nullptr, nullptr, stream, 0, scratch, kslices);
+}
+
+extern "C" int dv_conv2d_wino_cat_pair_ksplit_f32(const float* const* inputs, const int* channels, int n_inputs,
+                                                  const float* wpacked, const float* ch_scale, const float* ch_bias,
+                                                  const float* residual1, const float* mul1, float* out1,
+                                                  const float* residual2, const float* mul2, float* out2, float* scratch,
+                                                  int kslices, int B, int H, int W, int Cout1, int Cout2, int act,
+                                                  dv_stream_t stream) {
+  DV_REQUIRE_PTR(out2);
+  DV_REQUIRE_PTR(scratch);
+  DV_REQUIRE(Cout1 > 0 && Cout2 > 0 && Cout1 % 32 == 0, DV_ERR_SHAPE);
+  return wino2d_launch(inputs, channels, n_inputs, wpacked, ch_scale, ch_bias, residual1, mul1, nullptr, nullptr, out1, B,
+                       H, W, Cout1 + Cout2, 1, act, Cout1, residual2, mul2, out2, stream, 0, scratch, kslices);
 }
 
 extern "C" int dv_conv2d_wino_dil_cat_f32(const float* const* inputs, const int* channels, int n_inputs,
@@ -635,7 +739,7 @@ int wino2d_launch(const float* const* inputs, const int* channels, int n_inputs,
                   const float* ch_scale, const float* ch_bias, const float* residual, const float* mul,
                   const float* blend_z, const float* blend_h, float* out, int B, int H, int W, int Cout, int dilation,
                   int act, int gsplit, const float* residual2, const float* mul2, float* out2, dv_stream_t stream,
-                  int s2b) {
+                  int s2b, float* scratch, int kslices) {
   DV_REQUIRE_PTR(inputs);
   DV_REQUIRE(dilation >= 1 && dilation <= 16, DV_ERR_UNSUPPORTED);
   DV_REQUIRE_PTR(channels);
@@ -673,7 +777,11 @@ int wino2d_launch(const float* const* inputs, const int* channels, int n_inputs,
     a.fast_ok = (W % 4 == 0) && dv_aligned16(out);
   }
   a.ntx = cdiv2(cdiv2(W, dilation), w2::TW); a.nty = cdiv2(cdiv2(H, dilation), w2::TH); a.nco = cdiv2(Cout, 32);
-  const long long blocks = (long long)B * a.nco * a.nty * a.ntx * dilation * dilation;
+  a.kslices = kslices; a.scratch = scratch;
+  if (kslices != 1) {
+    DV_REQUIRE(scratch != nullptr && !s2b && kslices == wino2d_kslices(cin, H, W, Cout, dilation), DV_ERR_UNSUPPORTED);
+  }
+  const long long blocks = (long long)B * a.nco * a.nty * a.ntx * dilation * dilation * kslices;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return DV_ERR_SHAPE;
   // launches that leave most of the chip empty run the deep-prefetch variant
 #ifndef DV_W2_DEEP_BELOW
@@ -687,6 +795,17 @@ int wino2d_launch(const float* const* inputs, const int* channels, int n_inputs,
   void (*kern)(Wino2dArgs) =
       deep ? (src_mode == 0 ? conv2d_wino_kernel<true, 0> : src_mode == 1 ? conv2d_wino_kernel<true, 1> : conv2d_wino_kernel<true, 2>)
            : (src_mode == 0 ? conv2d_wino_kernel<false, 0> : src_mode == 1 ? conv2d_wino_kernel<false, 1> : conv2d_wino_kernel<false, 2>);
+  if (kslices > 1) {
+    void (*kk)(Wino2dArgs) = src_mode == 0 ? conv2d_wino_kernel<true, 0, true>
+                             : src_mode == 1 ? conv2d_wino_kernel<true, 1, true> : conv2d_wino_kernel<true, 2, true>;
+    hipLaunchKernelGGL(kk, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    const int rc = dv_launch_status();
+    if (rc != DV_OK) return rc;
+    const size_t oplane = (size_t)H * W, total = (size_t)B * Cout * oplane;
+    hipLaunchKernelGGL(wino2d_ksplit_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, a, total, oplane);
+    return dv_launch_status();
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   return dv_launch_status();
 }

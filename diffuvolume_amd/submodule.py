@@ -694,6 +694,18 @@ class Conv2dPairPlan:
         lib = _lib.load()
         n_out = outs[0].numel() + outs[1].numel()
         extra = sum(t.numel() for t in res + mu if t is not None)
+        ks = lib.dv_conv2d_wino_auto_kslices(self.cin, h, w, self.c1 + self.c2, 1) if Conv2dPlan.KSPLIT else 1
+        if ks > 1:            # a launch that leaves most of the chip empty: K-split, partial tiles in scratch, fixed-order sum
+            scratch = torch.empty(ks * n_out, dtype=torch.float32, device=parts[0].device)
+            with torch.cuda.device(parts[0].device):
+                timed(f"conv2d_k3d1_co{self.c1}+{self.c2}_ksplit", 2.0 * n_out * self.cin * 9,
+                      4.0 * (sum(t.numel() for t in parts) + n_out * (1 + 2 * ks) + extra),
+                      lambda: _lib.check(lib.dv_conv2d_wino_cat_pair_ksplit_f32(
+                          ptrs, chans, len(parts), self.packed.data_ptr(), _lib.ptr(self.scale), _lib.ptr(self.shift),
+                          _lib.ptr(res[0]), _lib.ptr(mu[0]), outs[0].data_ptr(), _lib.ptr(res[1]), _lib.ptr(mu[1]),
+                          outs[1].data_ptr(), scratch.data_ptr(), ks, b, h, w, self.c1, self.c2, self.act, _lib.stream_ptr()),
+                          "dv_conv2d_wino_cat_pair_ksplit_f32"), issued=2.0 * n_out * self.cin * 9 / WINO_MULT_REDUCTION)
+            return outs[0], outs[1]
         with torch.cuda.device(parts[0].device):
             timed(f"conv2d_k3d1_co{self.c1}+{self.c2}", 2.0 * n_out * self.cin * 9, 4.0 * (sum(t.numel() for t in parts) + n_out + extra),
                   lambda: _lib.check(lib.dv_conv2d_wino_cat_pair_f32(ptrs, chans, len(parts), self.packed.data_ptr(),
@@ -824,6 +836,18 @@ class Conv2dPlan:
             srcs = parts if parts is not None else [x]
             ptrs = (ctypes.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
             chans = (ctypes.c_int * len(srcs))(*[t.shape[1] for t in srcs])
+            ks = lib.dv_conv2d_wino_auto_kslices(cin, h, w, self.cout, d) if (self.KSPLIT and group == 1) else 1
+            if ks > 1:        # (see Conv2dPairPlan)
+                scratch = torch.empty(ks * out.numel(), dtype=torch.float32, device=x.device)
+                with torch.cuda.device(x.device):
+                    nb = 4.0 * (sum(t.numel() for t in srcs) + out.numel() * (1 + extra + 2 * ks))
+                    timed(f"conv2d_k3d{d}_co{self.cout}_wksplit", 2.0 * out.numel() * cin * 9, nb,
+                          lambda: _lib.check(lib.dv_conv2d_wino_cat_ksplit_f32(
+                              ptrs, chans, len(srcs), self.wino_packed.data_ptr(), _lib.ptr(self.scale), _lib.ptr(self.shift),
+                              _lib.ptr(residual), _lib.ptr(mul), _lib.ptr(bz), _lib.ptr(bh), out.data_ptr(), scratch.data_ptr(),
+                              ks, b, h, w, self.cout, d, self.act, _lib.stream_ptr()), "dv_conv2d_wino_cat_ksplit_f32"),
+                          issued=2.0 * out.numel() * cin * 9 / WINO_MULT_REDUCTION)
+                return out
             with torch.cuda.device(x.device):
                 nb = 4.0 * (sum(t.numel() for t in srcs) + out.numel() * (1 + extra))
                 timed(f"conv2d_k3d{d}_co{self.cout}", 2.0 * out.numel() * cin * 9, nb,

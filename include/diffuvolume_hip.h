@@ -266,6 +266,21 @@ int dv_refine_inputs_f32(const float* left, const float* right, const float* dis
                          const float* du_b, float* out, int B, int C, int H, int W, int maxshift,
                          dv_stream_t stream);
 
+/* K-split forms of the two Winograd entries above, for launches that leave most of the chip empty (IGEV's ConvGRU at 1/16
+ * resolution: 80 / 40 blocks per pair): `kslices` = dv_conv2d_wino_auto_kslices(Cin, H, W, Cout, dilation) blocks share an
+ * output tile, each sums a contiguous range of the input-channel chunks into scratch [kslices][B,Cout,H,W] (Cout = Cout1 + Cout2
+ * for the pair), and a second kernel adds the slices in slice order (deterministic) and applies the epilogue.  The factor
+ * depends on ONE batch item only, so a shard of a batch reproduces the batch's bits.  kslices == 1: use the entries above. */
+int dv_conv2d_wino_auto_kslices(int Cin, int H, int W, int Cout, int dilation);
+int dv_conv2d_wino_cat_ksplit_f32(const float* const* inputs, const int* channels, int n_inputs, const float* wpacked,
+                                  const float* ch_scale, const float* ch_bias, const float* residual, const float* mul,
+                                  const float* blend_z, const float* blend_h, float* out, float* scratch, int kslices, int B,
+                                  int H, int W, int Cout, int dilation, int act, dv_stream_t stream);
+int dv_conv2d_wino_cat_pair_ksplit_f32(const float* const* inputs, const int* channels, int n_inputs, const float* wpacked,
+                                       const float* ch_scale, const float* ch_bias, const float* residual1, const float* mul1,
+                                       float* out1, const float* residual2, const float* mul2, float* out2, float* scratch,
+                                       int kslices, int B, int H, int W, int Cout1, int Cout2, int act, dv_stream_t stream);
+
 /* Space-to-batch for the dilated layers of refinenet_version3 (KITTI12/models/pwcnet_ddim.py:251-306), csrc/refine_inputs.hip.
  * dv_space_to_batch2_f32: [N,C,h,w] -> [4N,C,h/2,w/2]; sub-image (y & 1, x & 1) of item n becomes item 4n + 2(y & 1) + (x & 1)
  *   (h, w even; `in` 8-byte aligned).  A 3x3 convolution with dilation 2d on the input is one with dilation d on the output.

@@ -326,9 +326,11 @@ def test_gru_gate_pair_launch_equals_the_two_convolutions(shape):
     z, rh = pair(parts, residual=(cz, cr), mul=(None, parts[0]))
     z1 = S.Conv2dPlan(w1, None, act=S.ACT_SIGMOID, bias=b1)(parts, residual=cz)
     rh1 = S.Conv2dPlan(w2, None, act=S.ACT_SIGMOID, bias=b2)(parts, residual=cr, mul=parts[0])
-    if -(-h // 16) * -(-w // 16) * 4 >= S.Conv2dPlan.WINO_MIN_BLOCKS:            # (per batch item) the single launches are Winograd too
-        assert torch.equal(z, z1) and torch.equal(rh, rh1)
-    else:                                                                        # they ran the direct / K-split kernel
+    from diffuvolume_amd import _lib
+    ks = [_lib.load().dv_conv2d_wino_auto_kslices(384, h, w, c, 1) for c in (256, 128)]
+    if -(-h // 16) * -(-w // 16) * 4 >= S.Conv2dPlan.WINO_MIN_BLOCKS and ks[0] == ks[1]:
+        assert torch.equal(z, z1) and torch.equal(rh, rh1)                       # (per batch item) the single launches are Winograd too
+    else:                                                     # they ran the direct kernel / another K-split: another order of summation
         assert rel_err(z, z1.cpu()) < 1e-5 and rel_err(rh, rh1.cpu()) < 1e-5
     ref = torch.sigmoid(F.conv2d(torch.cat(parts, 1).double().cpu(), w2.double().cpu(), b2.double().cpu(), padding=1)
                         + cr.double().cpu()) * parts[0].double().cpu()
@@ -423,3 +425,40 @@ def test_front_kernels_vs_torch():
     assert a.shape == ref.shape and float((a.double() - ref).abs().max() / ref.abs().max()) < 2e-5
     with pytest.raises(_lib.DiffuVolumeError):
         I.hip_conv2d(nn.Conv2d(8, 8, 5, padding=2).to(DEV), torch.zeros(1, 8, 8, 8, device=DEV))
+
+
+@pytest.mark.parametrize("cfg", [((128, 128), 24, 78, 4), ((128, 128, 128), 12, 40, 2), ((130, 61, 3), 24, 78, 1), ((256,), 20, 36, 3)])
+def test_winograd_ksplit_small_launches(cfg):
+    """The K-split form of the Winograd launches (csrc/conv2d_wino.hip, `dv_conv2d_wino_cat_ksplit_f32` /
+    `..._pair_ksplit_f32`: IGEV's ConvGRU at 1/16 resolution, KITTI15/core/update.py:26-40): every source mode of the virtual
+    concatenation, the gate pair and the candidate with its blend epilogue against float64; the slices are summed in a fixed
+    order (rerun bit-equal) and their number depends on one batch item only (a shard reproduces the batch's bits)."""
+    from diffuvolume_amd import _lib
+    split, h, w, b = cfg
+    cin = sum(split)
+    g = _gen(91, "wksplit")
+    parts = [dev(torch.randn(b, c, h, w, generator=g)) for c in split]
+    w1, w2, wq = (dev(torch.randn(128, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5) for _ in range(3))
+    b1, b2, bq = (dev(torch.randn(128, generator=g) * 0.1) for _ in range(3))
+    cz, cr, cq = (dev(torch.randn(b, 128, h, w, generator=g)) for _ in range(3))
+    hh = dev(torch.randn(b, 128, h, w, generator=g))
+    lib = _lib.load()
+    assert lib.dv_conv2d_wino_auto_kslices(cin, h, w, 256, 1) > 1 and lib.dv_conv2d_wino_auto_kslices(cin, h, w, 128, 1) > 1
+    pair = S.Conv2dPairPlan((w1, b1), (w2, b2), S.ACT_SIGMOID)
+    pq = S.Conv2dPlan(wq, None, act=S.ACT_TANH, bias=bq)
+    z, rh = pair(parts, residual=(cz, cr), mul=(None, hh))
+    q = pq(parts, residual=cq, blend=(z, hh))
+    x = torch.cat(parts, 1).double().cpu()
+    conv = lambda wt, bt: F.conv2d(x, wt.double().cpu(), bt.double().cpu(), padding=1)
+    zr = torch.sigmoid(conv(w1, b1) + cz.double().cpu())
+    rr = torch.sigmoid(conv(w2, b2) + cr.double().cpu()) * hh.double().cpu()
+    assert rel_err(z, zr) < 1e-5 and rel_err(rh, rr) < 1e-5
+    qr = hh.double().cpu() + z.double().cpu() * (torch.tanh(conv(wq, bq) + cq.double().cpu()) - hh.double().cpu())
+    assert rel_err(q, qr) < 1e-5
+    z2, rh2 = pair(parts, residual=(cz, cr), mul=(None, hh))
+    assert torch.equal(z, z2) and torch.equal(rh, rh2) and torch.equal(q, pq(parts, residual=cq, blend=(z, hh)))
+    if b > 1:
+        sl = slice(b - 1, b)
+        z1, rh1 = pair([t[sl].contiguous() for t in parts], residual=(cz[sl].contiguous(), cr[sl].contiguous()),
+                       mul=(None, hh[sl].contiguous()))
+        assert torch.equal(z1, z[sl]) and torch.equal(rh1, rh[sl])

@@ -52,6 +52,16 @@ __global__ __launch_bounds__(256) void conv2d_1in_kernel(const float* __restrict
 }
 
 // PyTorch's align_corners=True source index: src = dst * (in - 1) / (out - 1)  (0 when out == 1)
+__device__ __forceinline__ float resize_ac_at(const float* __restrict__ p, int h, int w, float sy, float sx, int Y, int X) {
+  const float fy = sy * (float)Y, fx = sx * (float)X;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  return hy * (hx * p[(size_t)y0 * w + x0] + lx * p[(size_t)y0 * w + x1]) +
+         ly * (hx * p[(size_t)y1 * w + x0] + lx * p[(size_t)y1 * w + x1]);
+}
+
 __global__ void resize_bilinear_ac_kernel(const float* __restrict__ in, float* __restrict__ out, int h, int w, int H,
                                           int W, size_t total) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -60,14 +70,27 @@ __global__ void resize_bilinear_ac_kernel(const float* __restrict__ in, float* _
   const int Y = (int)((i / W) % H);
   const size_t bc = i / ((size_t)W * H);
   const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
-  const float fy = sy * (float)Y, fx = sx * (float)X;
-  const int y0 = (int)fy, x0 = (int)fx;
-  const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
-  const float ly = fy - (float)y0, lx = fx - (float)x0;
-  const float hy = 1.f - ly, hx = 1.f - lx;
+  out[i] = resize_ac_at(in + bc * (size_t)h * w, h, w, sy, sx, Y, X);
+}
+
+// the same, four consecutive outputs of a row per thread (W % 4 == 0, 16-byte aligned rows): the kernel is its stores --
+// `interp` writes the 1/4-resolution hidden state once per GRU iteration (61 MB at batch 4)
+__global__ void resize_bilinear_ac_x4_kernel(const float* __restrict__ in, float* __restrict__ out, int h, int w, int H,
+                                             int W, size_t total4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int W4 = W >> 2;
+  const int X = (int)(i % W4) * 4;
+  const int Y = (int)((i / W4) % H);
+  const size_t bc = i / ((size_t)W4 * H);
+  const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
   const float* p = in + bc * (size_t)h * w;
-  out[i] = hy * (hx * p[(size_t)y0 * w + x0] + lx * p[(size_t)y0 * w + x1]) +
-           ly * (hx * p[(size_t)y1 * w + x0] + lx * p[(size_t)y1 * w + x1]);
+  float4 v;
+  v.x = resize_ac_at(p, h, w, sy, sx, Y, X);
+  v.y = resize_ac_at(p, h, w, sy, sx, Y, X + 1);
+  v.z = resize_ac_at(p, h, w, sy, sx, Y, X + 2);
+  v.w = resize_ac_at(p, h, w, sy, sx, Y, X + 3);
+  *reinterpret_cast<float4*>(out + (bc * H + Y) * (size_t)W + X) = v;
 }
 
 // 3x3 average, stride 2, padding 1, padded zeros counted (divisor 9): out = floor((in + 2 - 3) / 2) + 1
@@ -124,6 +147,12 @@ extern "C" int dv_resize_bilinear_ac_f32(const float* in, float* out, int BC, in
   DV_REQUIRE(BC > 0 && h > 0 && w > 0 && H > 0 && W > 0, DV_ERR_SHAPE);
   const size_t total = (size_t)BC * H * W;
   DV_REQUIRE((total + 255) / 256 <= 0x7fffffffull, DV_ERR_SHAPE);
+  if (W % 4 == 0 && dv_aligned16(out)) {
+    const size_t total4 = total / 4;
+    hipLaunchKernelGGL(resize_bilinear_ac_x4_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, in, out, h, w, H, W, total4);
+    return dv_launch_status();
+  }
   hipLaunchKernelGGL(resize_bilinear_ac_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      in, out, h, w, H, W, total);
   return dv_launch_status();

@@ -427,18 +427,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
   float* const outp = g2 ? a.out2 : a.out;
   const float* const resp = g2 ? a.residual2 : a.residual;
   const float* const mulp = g2 ? a.mul2 : a.mul;
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int co = co0 + n * 16 + j;
-    if (co >= a.Cout) continue;
-    const float sc = a.ch_scale ? a.ch_scale[co] : 1.f;
-    const float bi = a.ch_bias ? a.ch_bias[co] : 0.f;
-    const size_t cbase = (((size_t)b * coutg + (co - cog0)) * a.H + (ry + dil * yb)) * a.W + (rx + dil * xb);
-    // At M A on packed fp32 over the two tile rows (elements 2h, 2h+1 of every accumulator are an aligned register pair;
-    // conv3d_wino.hip), then the rows: the plain ReLU / identity layers (feature CNNs, refinement stack, motion encoder)
-    // take a path whose uniform decisions are made once, the gate epilogues (sigmoid / tanh, `mul`, GRU blend) the
-    // general one.  An epilogue instruction is not hidden by the other block's MFMAs -- they share the issue pipe.
-    f32x2 yq2[2][2][2];                    // [tile column h][row of the tile][column of the tile] over (tile row 0, 1)
+  typedef f32x2 TileSums[2][2][2];       // [tile column h][row of the tile][column of the tile] over (tile row 0, 1)
+  // At M A on packed fp32 over the two tile rows (elements 2h, 2h+1 of every accumulator are an aligned register pair;
+  // conv3d_wino.hip)
+  auto tile_sums = [&](int n, TileSums& yq2) __attribute__((always_inline)) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       f32x2 s0[4], s1[4];
@@ -456,6 +448,19 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
       yq2[h][1][0] = s1[0] + s1[1] + s1[2];
       yq2[h][1][1] = s1[1] - s1[2] - s1[3];
     }
+  };
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int co = co0 + n * 16 + j;
+    if (co >= a.Cout) continue;
+    const float sc = a.ch_scale ? a.ch_scale[co] : 1.f;
+    const float bi = a.ch_bias ? a.ch_bias[co] : 0.f;
+    const size_t cbase = (((size_t)b * coutg + (co - cog0)) * a.H + (ry + dil * yb)) * a.W + (rx + dil * xb);
+    // the rows: the plain ReLU / identity layers (feature CNNs, refinement stack, motion encoder) take a path whose uniform
+    // decisions are made once, everything else the general one.  An epilogue instruction is not hidden by the other
+    // block's MFMAs -- they share the issue pipe.
+    TileSums yq2;
+    tile_sums(n, yq2);
     if (KS) {      // raw tile sums of this slice -> scratch[slice][B, Cout, H, W]; the epilogue runs in the reduction kernel
       float* sp = a.scratch + (size_t)slice * ((size_t)a.B * a.Cout * plane) +
                   (((size_t)b * a.Cout + co) * a.H + (ry + dil * yb)) * a.W + (rx + dil * xb);
@@ -527,6 +532,36 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(Wino2dArgs a) {
         if (resp) plain_rows(std::false_type{}, std::true_type{});
         else plain_rows(std::false_type{}, std::false_type{});
       }
+      continue;
+    }
+    // the gate epilogues of ConvGRU (sigmoid [* h], tanh + blend) on full aligned tiles: the non-linearity is a compile-time
+    // choice per block (hardware exponential / reciprocal, dv_common.h), the operand decisions are made per row.  Measured
+    // and NOT kept: every operand row of a tile (or of both tiles) requested in front of the output transform -- slower
+    // (0.895 / 0.493 ms against 0.871 / 0.475 for the z|r and q launches of gru04), the rows as they come are the best order.
+    auto gate_rows = [&](auto act_c) __attribute__((always_inline)) {
+      constexpr int ACT = decltype(act_c)::value;
+#pragma unroll
+      for (int tr = 0; tr < 2; ++tr) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const size_t o = cbase + (size_t)(2 * tr + r) * a.W;
+          f32x4 v = (f32x4){yq2[0][r][0][tr], yq2[0][r][1][tr], yq2[1][r][0][tr], yq2[1][r][1][tr]} * sc + bi;
+          if (resp) v += *reinterpret_cast<const f32x4*>(resp + o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = ACT == DV_ACT_SIGMOID ? dv_sigmoid(v[e]) : dv_tanh(v[e]);
+          if (mulp) v *= *reinterpret_cast<const f32x4*>(mulp + o);
+          if (a.blend_z) {
+            const f32x4 z = *reinterpret_cast<const f32x4*>(a.blend_z + o);
+            const f32x4 h = *reinterpret_cast<const f32x4*>(a.blend_h + o);
+            v = h + z * (v - h);
+          }
+          *reinterpret_cast<f32x4*>(outp + o) = v;
+        }
+      }
+    };
+    if (fast && !a.s2b && (a.act == DV_ACT_SIGMOID || a.act == DV_ACT_TANH)) {
+      if (a.act == DV_ACT_SIGMOID) gate_rows(std::integral_constant<int, DV_ACT_SIGMOID>{});
+      else gate_rows(std::integral_constant<int, DV_ACT_TANH>{});
       continue;
     }
 #pragma unroll

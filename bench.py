@@ -173,9 +173,8 @@ def launch_workers(a, argv):
         if n_vis < a.gpus:
             print(f"bench.py: --gpus {a.gpus} but only {n_vis} GPU(s) visible; refusing to measure fewer", file=sys.stderr)
             return 2
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    from diffuvolume_amd.distributed import free_port
+    port = free_port()
     procs = []
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",

@@ -62,3 +62,22 @@ def barrier_and_max(seconds: float, device) -> float:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
     return seconds
+
+
+def free_port(lo: int = 20000, hi: int = 30000, tries: int = 64) -> int:
+    """A TCP port on 127.0.0.1 for a rendezvous, taken from BELOW the kernel's ephemeral range (32768-60999 on Linux): a port
+    found by bind(0) is released before the rank-0 store binds it again, and any outgoing connection made in between -- RCCL /
+    gloo sockets of another test, for instance -- may be handed the same number (`EADDRINUSE`, seen once in a full GPU suite).
+    Ports in [lo, hi) are only ever taken by an explicit bind."""
+    import random
+    import socket
+    rng = random.Random()
+    for _ in range(tries):
+        port = rng.randrange(lo, hi)
+        with socket.socket() as sk:
+            try:
+                sk.bind(("127.0.0.1", port))
+            except OSError:
+                continue
+            return port
+    raise RuntimeError(f"no free TCP port found in [{lo}, {hi})")

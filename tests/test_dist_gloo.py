@@ -10,9 +10,8 @@ import torch.multiprocessing as mp
 
 
 def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    from diffuvolume_amd.distributed import free_port
+    return free_port()
 
 
 def _batches():

@@ -17,9 +17,8 @@ ROOT = Path(__file__).resolve().parents[1]
 
 
 def _env():
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    from diffuvolume_amd.distributed import free_port
+    port = free_port()
     e = {k: v for k, v in os.environ.items() if k not in ("DV_DIST_BACKEND", "DV_BENCH_SELF_LAUNCHED")}
     e.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
              HSA_ENABLE_IPC_MODE_LEGACY="0")

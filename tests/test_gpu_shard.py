@@ -21,9 +21,8 @@ def test_two_process_shards_match_single_process():
     sys.path.insert(0, str(ROOT / "tests"))
     import shard_worker as W
     from diffuvolume_amd import metrics as M
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    from diffuvolume_amd.distributed import free_port
+    port = free_port()
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",

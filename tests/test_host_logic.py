@@ -180,3 +180,13 @@ def test_origin_and_pcw_state_dict_layouts():
     # SceneFlow/models/__init__.py + KITTI12/models/__init__.py:5-9
     assert sorted(__models__) == ["acvnet", "acvnet_ddim", "gwcnet-g", "gwcnet-gc", "pwc_ddimgc"]
     assert len(__models__["gwcnet-gc"](192).state_dict()) == 887 and len(__models__["gwcnet-g"](192).state_dict()) == 859
+
+
+def test_rendezvous_port_below_the_ephemeral_range():
+    """distributed.free_port: a rendezvous port that no outgoing connection can be handed in the meantime."""
+    import socket
+    from diffuvolume_amd.distributed import free_port
+    ports = {free_port() for _ in range(8)}
+    assert all(20000 <= p < 30000 for p in ports)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", next(iter(ports))))          # still free

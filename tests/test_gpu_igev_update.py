@@ -462,3 +462,28 @@ def test_winograd_ksplit_small_launches(cfg):
         z1, rh1 = pair([t[sl].contiguous() for t in parts], residual=(cz[sl].contiguous(), cr[sl].contiguous()),
                        mul=(None, hh[sl].contiguous()))
         assert torch.equal(z1, z[sl]) and torch.equal(rh1, rh[sl])
+
+
+@pytest.mark.parametrize("act", ["sigmoid", "tanh"])
+def test_gate_nonlinearities_accuracy(act):
+    """dv_sigmoid / dv_tanh (csrc/dv_common.h: hardware exponential + reciprocal, tanh by its odd series below 1/8) against
+    float64 over the whole range, through an identity 1x1 convolution (exact in fp32): relative error <= 1e-6 where the
+    function is not saturated, no cancellation near 0, saturation to +-1 / 0 / 1, NaN stays NaN."""
+    c = 32
+    mags = torch.cat([torch.logspace(-30, -6, 64), torch.logspace(-6, 2, 4000), torch.tensor([0.0, 0.124999, 0.125, 0.125001, 88.0, 1e4, 3e38])])
+    v = torch.cat([mags, -mags])
+    n = v.numel()
+    h, w = 16, -(-n // 16)
+    flat = torch.zeros(h * w)
+    flat[:n] = v
+    x = flat.view(1, 1, h, w).repeat(1, c, 1, 1).contiguous()
+    wt = torch.eye(c).view(c, c, 1, 1)
+    plan = S.Conv2dPlan(dev(wt), None, act=S.ACT_SIGMOID if act == "sigmoid" else S.ACT_TANH)
+    out = plan(dev(x)).cpu().double()[0, 3].reshape(-1)[:n]
+    ref = torch.sigmoid(v.double()) if act == "sigmoid" else torch.tanh(v.double())
+    rel = ((out - ref).abs() / ref.abs().clamp(min=1e-300))
+    ok = ref.abs() > 1e-30                                # (sigmoid of a large negative argument underflows to 0 like the reference)
+    assert float(rel[ok].max()) < 1e-6, (act, float(rel[ok].max()), float(v[ok][rel[ok].argmax()]))
+    assert float((out - ref).abs().max()) < 2e-7
+    xn = torch.full((1, c, 4, 4), float("nan"))
+    assert bool(torch.isnan(plan(dev(xn))).all())

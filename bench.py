@@ -589,6 +589,8 @@ def main_flavour(a, rank, world, device):
                                "note": "dominant matrix-pipe kernel of this workload by HIP-event time (KernelTimer tag); "
                                        "issued flops / time over the fp32 MFMA peak"}
         out["kernels_ms_per_step"] = {k: round(v["total_ms"] / a.steps, 3) for k, v in sorted(ks.items())}
+        out["kernels_issued_frac_of_mfma_f32_peak"] = {k: round(v["issued_flops"] / v["total_ms"] / 1e9 / PEAK_MFMA_F32_TFLOPS, 3)
+                                                       for k, v in sorted(mf.items()) if v["total_ms"] > 0}
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
     if rank == 0:

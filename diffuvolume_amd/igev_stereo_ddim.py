@@ -137,8 +137,7 @@ class IGEVDiffusionLoop:
             coords1 = coords1 + flow_init
         flow_up = None
         # mask_feat_4 is read only after the last iteration (:255-259): this build's update block can skip it elsewhere.
-        # (Measured and not kept: lookup + motion encoder on a second stream beside gru16 / gru08 -- 3.5 % slower at
-        # batch 4, the co-running kernels and the two cross-stream joins per iteration cost more than the idle CUs.)
+        # (The update block runs lookup + motion encoder on a side stream beside gru16 / gru08: update.py, OVERLAP.)
         from .update import BasicMultiUpdateBlock
         skip_mask = isinstance(self.update_block, BasicMultiUpdateBlock)
         for itr in range(iters):

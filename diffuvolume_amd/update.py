@@ -220,6 +220,17 @@ class BasicMultiUpdateBlock(_Planned):
     def _build(self):
         return _plan(self.mask_feat_4[0], ACT_RELU)
 
+    import os as _os
+    OVERLAP = _os.environ.get("DV_IGEV_OVERLAP", "1") != "0"
+    _streams = None
+
+    def _side_stream(self, device):
+        if self._streams is None:
+            object.__setattr__(self, "_streams", {})
+        if device not in self._streams:
+            self._streams[device] = torch.cuda.Stream(device=device)
+        return self._streams[device]
+
     def forward(self, net, inp, corr=None, disp=None, iter04=True, iter08=True, iter16=True, update=True,
                 mask=True):
         """The reference's call (update.py:119-142) plus `mask=False` to skip `mask_feat_4`, which the reference computes
@@ -227,6 +238,26 @@ class BasicMultiUpdateBlock(_Planned):
         if self.training:
             raise NotImplementedError("the MI355X update block is inference-only (model.eval())")
         with torch.no_grad():
+            mf = None
+            if self.OVERLAP and iter04 and iter08 and corr is not None and disp.is_cuda and \
+                    not torch.cuda.is_current_stream_capturing():
+                # The motion encoder (lookup + five convolutions) does not depend on gru16 / gru08: it runs on a side stream
+                # beside them, filling their ramp-up / tail gaps and the half-empty 1/16-scale launches.  Same kernels on the
+                # same inputs: bit-identical.  Round 5, batch 4, 1248x384, 20 x 32 iterations, same box, alternating:
+                # 1 806-1 807 ms on one stream, 1 775 ms with the encoder on the side stream (-1.8 %; the same experiment was
+                # 3.5 % SLOWER before the lookup was coalesced and the small launches K-split).  Measured and NOT kept: gru16 of
+                # the next iteration on the side stream beside gru04 and the disparity head (it only needs net[2] and
+                # pool2x(net[1]), final after gru08): 1 786-1 789 ms -- gru04 fills the chip, the extra launches only contend.
+                # DV_IGEV_OVERLAP=0 puts everything back on one stream.
+                main = torch.cuda.current_stream(disp.device)
+                side = self._side_stream(disp.device)
+                side.wait_stream(main)
+                for t in (disp, *(getattr(corr, n, None) for n in ("disp", "coords", "noisy"))):
+                    if isinstance(t, torch.Tensor):
+                        t.record_stream(side)                    # (main-stream tensors the side stream reads)
+                with torch.cuda.stream(side):
+                    mf = self.encoder.features(disp, corr)
+                mf.record_stream(main)
             if iter16:
                 net[2] = self.gru16(net[2], *(inp[2]), pool2x(net[1]))
             if iter08:
@@ -235,7 +266,10 @@ class BasicMultiUpdateBlock(_Planned):
                 else:
                     net[1] = self.gru08(net[1], *(inp[1]), pool2x(net[0]))
             if iter04:
-                mf = self.encoder.features(disp, corr)               # [h | mf+disp | interp]: three sources, no cat
+                if mf is None:
+                    mf = self.encoder.features(disp, corr)           # [h | mf+disp | interp]: three sources, no cat
+                else:
+                    torch.cuda.current_stream(disp.device).wait_stream(self._side_stream(disp.device))
                 if self.args.n_gru_layers > 1:
                     net[0] = self.gru04(net[0], *(inp[0]), mf, interp(net[1], net[0]))
                 else:

@@ -487,3 +487,41 @@ def test_gate_nonlinearities_accuracy(act):
     assert float((out - ref).abs().max()) < 2e-7
     xn = torch.full((1, c, 4, 4), float("nan"))
     assert bool(torch.isnan(plan(dev(xn))).all())
+
+
+def test_update_block_side_stream_is_bit_identical():
+    """BasicMultiUpdateBlock runs the motion encoder on a side stream beside gru16 / gru08 (update.py, OVERLAP): the same
+    kernels on the same inputs -- three chained iterations are bit-equal to the one-stream run, with a tensor and with a
+    fused-lookup request as `corr`."""
+    from diffuvolume_amd.update import BasicMultiUpdateBlock
+    from diffuvolume_amd.geometry_ddim import Combined_Geo_Encoding_Volume
+    m = make_block(77)
+    b, h, w = 2, 24, 80
+    net, inp, corr, disp = update_inputs(78, b, h, w)
+    g = _gen(79, "side")
+    geo_fn = Combined_Geo_Encoding_Volume(dev(torch.randn(b, 16, h, w, generator=g)), dev(torch.randn(b, 16, h, w, generator=g)),
+                                          dev(torch.randn(b, 8, 48, h, w, generator=g)))
+    coords = dev(torch.arange(w, dtype=torch.float32).view(1, 1, 1, w).expand(b, 1, h, w).contiguous())
+    noisy = dev(torch.rand(b, 48, h, w, generator=g))
+
+    def run(overlap, use_request):
+        BasicMultiUpdateBlock.OVERLAP = overlap
+        nl = [dev(t).clone() for t in net]
+        il = [[dev(t) for t in l] for l in inp]
+        d = dev(disp).clone()
+        outs = []
+        for _ in range(3):
+            c = geo_fn.request(d, coords + d, noisy) if use_request else dev(corr)
+            nl, _, delta = m(nl, il, c, d, mask=False)
+            d = d + delta
+            outs.append(delta.clone())
+        torch.cuda.synchronize()
+        return [t.clone() for t in nl] + outs
+
+    keep = BasicMultiUpdateBlock.OVERLAP
+    try:
+        for use_request in (False, True):
+            a, c = run(False, use_request), run(True, use_request)
+            assert all(torch.equal(x, y) for x, y in zip(a, c))
+    finally:
+        BasicMultiUpdateBlock.OVERLAP = keep

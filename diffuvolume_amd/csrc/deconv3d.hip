@@ -10,11 +10,21 @@
 // convolution, but each tap accumulates into its class's accumulator.  A block owns a
 // 2 x 2 x 32 brick of INPUT positions (= 4 x 4 x 64 outputs) and 32 output channels; each wave
 // one input row, all 8 classes.  No zero-stuffing, no wasted MFMA work.
+#include <atomic>
 #include <type_traits>
 
 #include "dv_common.h"
 
+// csrc/deconv3d_pl.hip: the persistent loader-wave form of the k3 flavour (same packed weights)
+int dv_deconv3d_pl_run(const float* in, const float* wpacked, const float* ch_scale, const float* ch_bias, const float* residual,
+                       const float* skip, const float* rw, float* out, int B, int Cin, int D, int H, int W, int Cout, int Cskip,
+                       int act, size_t wpk_floats, hipStream_t s);
+
 namespace {
+
+// test hook (dv_deconv3d_set_impl): 0 = the launcher picks, 1 = one-tile blocks (deconv3d_mfma_kernel) always,
+// 2 = the persistent kernel wherever it takes the shape
+std::atomic<int> g_deconv_impl_pin{0};
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -498,10 +508,26 @@ int run_any(const float* in, const float* wpacked, const float* ch_scale, const 
   // fast epilogue: scalar row base + 32-bit per-lane byte offsets inside one batch item
   a.fast_ok = (W % 2 == 0) && dv_aligned16(out) && (!residual || dv_aligned16(residual)) &&
               (size_t)Cout * 8 * D * H * W * sizeof(float) <= 0xffffffffull;
+  // the persistent form (csrc/deconv3d_pl.hip) wherever it takes the shape.  The choice looks at one batch item only: a shard
+  // of a batch runs the kernel the batch runs.
+  const int pin = g_deconv_impl_pin.load(std::memory_order_relaxed);
+  // (with a residual tensor the epilogue's loads share the wave's in-order memory counter with its stores: the one-tile
+  // kernel's ring of residual rows handles that better; the persistent kernel takes it only when pinned)
+  if (K == 3 && pin != 1 && (pin == 2 || !residual) &&
+      dv_deconv3d_pl_supported(Cin, Cout, D, H, W, skip ? Cskip : 0) && dv_aligned16(in) && dv_aligned16(out) &&
+      (!residual || dv_aligned16(residual)) && (!skip || dv_aligned16(skip)))
+    return dv_deconv3d_pl_run(in, wpacked, ch_scale, ch_bias, residual, skip, rw, out, B, Cin, D, H, W, Cout, Cskip, act,
+                              dv_deconv3d_packed_floats(Cin, Cout), s);
   return K == 3 ? launch_deconv<3, 8>(a, s) : launch_deconv<4, 4>(a, s);
 }
 
 }  // namespace
+
+extern "C" int dv_deconv3d_set_impl(int mode) {
+  DV_REQUIRE(mode >= 0 && mode <= 2, DV_ERR_UNSUPPORTED);
+  g_deconv_impl_pin.store(mode, std::memory_order_relaxed);
+  return DV_OK;
+}
 
 extern "C" size_t dv_deconv3d_packed_floats(int Cin, int Cout) {
   if (Cin <= 0 || Cout <= 0) return 0;

@@ -1,0 +1,541 @@
+// K5p: ConvTranspose3d(k = 3, stride 2, padding 1, output_padding 1) + BN + skip + activation (hourglass conv5 / conv6,
+// SceneFlow/models/acv_ddim.py:74-80, :91-92; KITTI12/models/pwcnet_ddim.py:131-205) in the launch shape of
+// conv3d_s2pp.hip: ONE persistent block per CU, eight MFMA waves + loader waves.  Same arithmetic as deconv3d.hip
+// (parity decomposition: every tap feeds one of the 8 output parity classes, direct fp32 on v_mfma_f32_16x16x4_f32,
+// the fused `redir` 1x1x1 convolution of the skip tensor as extra K-steps), same packed weights.
+//
+// What is different from deconv3d.hip's one-tile blocks (its in-kernel stamps: 21.5 % of a block's life is epilogue, 11 %
+// first fetch + commit phases, and the CU's partner block fills those at the rate of one wave per SIMD):
+//   * the MFMA waves only read LDS, issue MFMAs and store; bricks and weight images arrive by LDS-DMA from loader waves
+//     (`buffer_load_dwordx4 ... lds`, the range check writes the zero padding), double-buffered, one block barrier per step;
+//   * a wave holds 64 accumulators (one input row x 16 positions x 32 output channels x 8 classes) instead of 128, so
+//     eleven waves of 168 registers fit a CU;
+//   * the eight MFMA waves are two GROUPS of four (a group = one tile of 1 x 2 x 32 input positions = 2 x 4 x 64 outputs
+//     x 32 output channels) that walk their tile lists NE steps apart: a step is one chunk of 8 input channels for a group
+//     that computes, or half an epilogue for a group that stores.  While one group stores, the other one computes -- the
+//     epilogue's stores leave the CU beside the partner group's MFMA stream by construction instead of by the luck of two
+//     independent blocks' phases, and no tile has a prologue: its first brick is copied during the previous tile's
+//     epilogue.
+#include <type_traits>
+
+#include "dv_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#ifndef DVPL_ABL
+#define DVPL_ABL 0     // timing-only ablations (results wrong): 1 no loader copies after step 1, 2 no stores, 4 no skip DMA, 8 no redir MFMAs, 16 no B reads in the tap loop
+#endif
+#ifndef DVPL_NL
+#define DVPL_NL 4
+#endif
+#ifndef DVPL_NE
+#define DVPL_NE 2
+#endif
+#ifndef DVPL_PRIO
+#define DVPL_PRIO 0    // 1: loader waves at priority 3; 2: epilogue steps at priority 2
+#endif
+namespace pl {
+constexpr int TH = 2, TW = 32, KC = 8, NT = 2, COUT = 16 * NT;
+constexpr int RQ = TW / 4 + 1;                 // quads of a brick row: x0 .. x0 + 35 (the +1 halo column is the first float of the last quad)
+constexpr int RS = 4 * RQ;                     // row stride (floats)
+constexpr int IY = TH + 1, ROWS = 2 * IY;      // two input planes x three rows
+constexpr int QPC = 60;                        // quads per channel: 54 loaded rows' quads + 6 zero quads; channel stride 240 floats == 48 (mod 64):
+constexpr int CS = 4 * QPC;                    //   the four k-lanes of an A read fall on disjoint banks
+static_assert(ROWS * RQ <= QPC && CS % 64 == 48, "brick image");
+constexpr int BRICK_Q = KC * QPC;              // 480 quads per chunk
+constexpr int BRICK_P = (BRICK_Q + 63) / 64;   // 8 DMA pieces (the last one half empty: its tail writes zeros behind the brick)
+constexpr int BRICK_FLOATS = BRICK_P * 256;
+constexpr int W_FLOATS = 27 * KC * COUT;       // the packed image of deconv3d.hip: [tap][kq][j][ks][n]
+constexpr int W_P = W_FLOATS / 256;            // 27 pieces
+static_assert(W_FLOATS % 256 == 0, "weight image in 1-KB pieces");
+constexpr int SKC = 4;                         // skip channels that ride on one chunk
+constexpr int SK_FLOATS = SKC * 4 * TW;        // a wave's skip tile: 4 channels x 4 output rows x 32 output columns
+constexpr int NL = DVPL_NL;                          // loader waves
+constexpr int NE = DVPL_NE;                          // steps of an epilogue = the distance between the two groups
+constexpr int NB = (BRICK_P + NL - 1) / NL, NW = (W_P + NL - 1) / NL;
+constexpr int MAXCO = 256;                     // output channels (scale / bias table in LDS)
+static_assert((2 * 2 * (W_FLOATS + BRICK_FLOATS) + 8 * SK_FLOATS + 2 * MAXCO) * 4 <= 160 * 1024, "one block per CU");
+static_assert(NE == 1 || NE == 2, "epilogue in one or two steps");
+}  // namespace pl
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// One 1-KB LDS-DMA piece (lane l: 16 bytes from buffer offset voff + soff to LDS address lds + 16 l) as inline assembly, for
+// the MFMA waves' own skip tiles: the compiler's wait-count pass does not see it, so it neither puts s_waitcnt vmcnt in front
+// of the LDS reads that follow (it did, whenever the builtin was not inside a run-time branch: the copy's latency exposed at
+// the top of every chunk) nor a draining fence at the barrier; the one wait this copy needs is written out where the tile is
+// read.  (Untracked OLDER operations only make the compiler's own counted waits wait longer than it thinks: in-order counter.)
+__device__ __forceinline__ void pl_dma16(i32x4 rsrc, unsigned lds, unsigned voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+__host__ __device__ constexpr int pl_par(int k) { return (k + 1) & 1; }
+__host__ __device__ constexpr int pl_off(int k) { return k == 0 ? 1 : 0; }
+
+struct PLArgs {
+  const float* in;
+  const float* wpk;
+  const float* ch_scale;
+  const float* ch_bias;
+  const float* residual;
+  const float* skip;
+  const float* rw;
+  float* out;
+  int B, Cin, D, H, W, Cout, Cskip;
+  int ntx, nty, nco, nsp;       // nsp: spatial tiles = B * D * nty * ntx
+  int act;
+  unsigned wpk_bytes;
+};
+
+#ifdef DVPL_STAMP
+__device__ unsigned long long g_pl_stamps[3 * 2 * 256];   // [wave 0 / 4 / 8 of block 0][step < 256][start, end]
+#define PL_STAMP(slot, s, e) do { if (blockIdx.x == 0 && (s) < 256 && lane == 0) g_pl_stamps[((slot) * 256 + (s)) * 2 + (e)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PL_STAMP(slot, s, e) do {} while (0)
+#endif
+
+struct PLTile { int tcb, xi, yi, z0, y0, x0, b; unsigned st; bool valid; };
+
+// AM: 0 = ReLU, 1 = max(v, slope v) (identity / LeakyReLU), 2 = Mish
+template <bool SKIP, bool RES, int AM>
+__global__ __launch_bounds__(512 + 64 * pl::NL, 1) void deconv3d_pl_kernel(PLArgs a) {
+  using namespace pl;
+  // (separate arrays: the MFMA waves' own LDS-DMA goes to sk_s only, so their reads of the other two never wait for it)
+  __shared__ __attribute__((aligned(16))) float w_s[2][2][W_FLOATS];        // [group][buffer]
+  __shared__ __attribute__((aligned(16))) float in_s[2][2][BRICK_FLOATS];
+  __shared__ __attribute__((aligned(16))) float sk_s[8][SK_FLOATS];
+  // BN scale / bias of every output channel.  They are read per tile; as vector-memory loads they would share the counter
+  // with the epilogue's stores (gfx9: stores count in vmcnt), and the compiler's conservative wait for them in front of an
+  // epilogue row also waits for the previous row's stores to be acknowledged (measured: 6-9 k cycles per half epilogue).
+  __shared__ float sb_s[2][MAXCO];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < a.Cout; i += 512 + 64 * NL) {
+    sb_s[0][i] = a.ch_scale ? a.ch_scale[i] : 1.f;
+    sb_s[1][i] = a.ch_bias ? a.ch_bias[i] : 0.f;
+  }
+
+  // ---- tile list.  A PAIR = two spatial tiles (x neighbours where the tile count along x is even) x ONE block of 32 output
+  // channels: group g computes spatial tile 2 SP + g.  (Both groups of a block walk the same weight chunks, two steps apart;
+  // one shared ring of four weight images instead of two double buffers -- 27 instead of 54 weight pieces per step -- was
+  // built and measured SLOWER, 1.78 vs 1.70 ms: profiles/r06_deconv_pl_experiments.txt.)  Pairs are ordered output-channel
+  // block fastest, then x, y, z, batch;
+  // every XCD owns a contiguous slab of that order (neighbours share bricks and halos in its L2) and its blocks walk it
+  // round-robin (as conv3d_s2pp.hip). ----
+  const unsigned nblk = gridDim.x, xcd = blockIdx.x & 7u, bidx = blockIdx.x >> 3;
+  const unsigned nbx = (nblk >> 3) + (xcd < (nblk & 7u) ? 1u : 0u);
+  const unsigned npairs = (((unsigned)a.nsp + 1u) >> 1) * (unsigned)a.nco;
+  const unsigned tq = npairs >> 3, trm = npairs & 7u;
+  const unsigned slab_lo = xcd < trm ? xcd * (tq + 1) : trm * (tq + 1) + (xcd - trm) * tq;
+  const unsigned slab_n = tq + (xcd < trm ? 1u : 0u);
+  const int my_pairs = __builtin_amdgcn_readfirstlane(bidx < slab_n ? (int)((slab_n - bidx + nbx - 1) / nbx) : 0);
+  if (my_pairs == 0) return;
+  // the block's pairs are nbx apart: the first one is decoded by division, the later ones by adding the stride's digits with
+  // carries (scalar adds and compares; the divisions would be vector-ALU work beside the partner group's MFMA stream)
+  auto rfl = [](unsigned v) __attribute__((always_inline)) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+  auto decode = [&](unsigned st, int (&d)[4]) __attribute__((always_inline)) {       // spatial tile -> x, y, z, batch
+    d[0] = (int)rfl(st % a.ntx); st /= a.ntx;
+    d[1] = (int)rfl(st % a.nty); st /= a.nty;
+    d[2] = (int)rfl(st % a.D);
+    d[3] = (int)rfl(st / a.D);
+  };
+  const int s_tc = (int)rfl(nbx % (unsigned)a.nco);
+  int sd[4];
+  decode(2u * (nbx / (unsigned)a.nco), sd);
+  auto tile_first = [&](int g) __attribute__((always_inline)) {
+    PLTile r;
+    const unsigned P = slab_lo + bidx;
+    r.tcb = (int)rfl(P % (unsigned)a.nco);
+    r.st = rfl(2u * (P / (unsigned)a.nco) + (unsigned)g);
+    r.valid = r.st < (unsigned)a.nsp;
+    int d[4];
+    decode(r.valid ? r.st : (unsigned)a.nsp - 1u, d);
+    r.xi = d[0]; r.yi = d[1]; r.z0 = d[2]; r.b = d[3];
+    r.x0 = r.xi * TW; r.y0 = r.yi * TH;
+    return r;
+  };
+  auto tile_next = [&](PLTile& r) __attribute__((always_inline)) {
+    r.tcb += s_tc;
+    const int c0 = r.tcb >= a.nco ? 1 : 0;
+    r.tcb -= c0 ? a.nco : 0;
+    r.st += 2u * (nbx / (unsigned)a.nco) + 2u * (unsigned)c0;
+    r.valid = r.st < (unsigned)a.nsp;                    // (past the end the digits are never used)
+    int c;
+    r.xi += sd[0] + 2 * c0; c = 0;
+    if (r.xi >= a.ntx) { r.xi -= a.ntx; c = 1; }
+    if (r.xi >= a.ntx) { r.xi -= a.ntx; c = 2; }
+    r.yi += sd[1] + c; c = 0;
+    if (r.yi >= a.nty) { r.yi -= a.nty; c = 1; }
+    if (r.yi >= a.nty) { r.yi -= a.nty; c = 2; }
+    r.z0 += sd[2] + c; c = 0;
+    if (r.z0 >= a.D) { r.z0 -= a.D; c = 1; }
+    if (r.z0 >= a.D) { r.z0 -= a.D; c = 2; }
+    r.b += sd[3] + c;
+    r.x0 = r.xi * TW; r.y0 = r.yi * TH;
+  };
+
+  const size_t plane = (size_t)a.H * a.W, vol = (size_t)a.D * plane;
+  const unsigned vol_bytes = (unsigned)__builtin_amdgcn_readfirstlane((int)(vol * sizeof(float)));
+  const int nchunk = a.Cin / KC;
+  const int PERIOD = nchunk + NE;                      // steps of a tile: its chunks, then the epilogue halves
+  const int n_total = my_pairs * PERIOD + NE;          // group 1 runs NE steps behind group 0
+
+  // Barrier protocol (all eleven waves): P, then one per step.  In step s a computing group reads the buffers of its chunk
+  // (its compute steps alternate between the two); the loaders copy what step s + 1 needs into the buffers step s does not
+  // read and wait for their copies before they arrive at the step's barrier.  The barriers are bare s_barrier instructions:
+  // __syncthreads() comes with a fence that drains vmcnt, i.e. an MFMA wave would wait at every step for its epilogue's
+  // stores to be acknowledged.  What has to be ordered is ordered by hand: LDS reads are consumed (lgkmcnt(0)) and the
+  // loaders' copies have landed (vmcnt(0)) before the barrier.
+  if (wave >= 8) {
+    // =========================== loader waves: global -> LDS by DMA, nothing else ===========================
+    const int li = wave - 8;
+    if (DVPL_PRIO & 1) __builtin_amdgcn_s_setprio(3);
+    const uint64_t wb = reinterpret_cast<uint64_t>(a.wpk);
+    const uint64_t wbs = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wb) |
+                         ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(wb >> 32)) << 32);
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(wbs), 0, (int)a.wpk_bytes, 0x00020000);
+    unsigned sob[2][NB];                                 // this lane's byte offset in each of the loader's brick pieces, per group
+    auto plan = [&](const PLTile& t, unsigned (&so)[NB]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int it = 64 * (li + NL * i) + lane;
+        const int cl = it / QPC, r1 = it - cl * QPC;
+        const int row = r1 / RQ, q = r1 - row * RQ;
+        const int zz = row / IY, yy = row - zz * IY;
+        const int z = t.z0 + zz, y = t.y0 + yy, x = t.x0 + 4 * q;
+        const bool ok = t.valid && it < BRICK_Q && row < ROWS && z < a.D && y < a.H && x < a.W;   // W % 4 == 0: a quad is inside or outside
+        so[i] = ok ? (unsigned)cl * vol_bytes + (unsigned)((z * a.H + y) * a.W + x) * 4u : 0xfffffff0u;
+      }
+    };
+    auto dma = [&](const PLTile& t, const unsigned (&so)[NB], int c, float* bdst, float* wdst, bool with_w) __attribute__((always_inline)) {
+      const uint64_t ba = reinterpret_cast<uint64_t>(a.in + ((size_t)t.b * a.Cin + (size_t)c * KC) * vol);
+      const uint64_t bu = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ba) |
+                          ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ba >> 32)) << 32);
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(bu), 0,
+                                                        __builtin_amdgcn_readfirstlane((int)((unsigned)KC * vol_bytes)), 0x00020000);
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        if (li + NL * i < BRICK_P && !(DVPL_ABL & 512))
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(bdst + (li + NL * i) * 256), 16,
+                                                   (int)so[i], 0, 0, 0);
+      const int wbase = (c * a.nco + t.tcb) * (W_FLOATS * 4);
+#pragma unroll
+      for (int i = 0; i < NW; ++i)
+        if (with_w && li + NL * i < W_P && !(DVPL_ABL & 256))
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(wdst + (li + NL * i) * 256), 16,
+                                                   lane * 16, wbase + (li + NL * i) * 1024, 0, 0);
+    };
+    // per group: the tile and phase of the NEXT step to prepare
+    PLTile ft[2] = {tile_first(0), tile_first(1)};
+    int fk[2] = {0, 0}, fp[2] = {0, 0}, fcc[2] = {0, 0};
+    plan(ft[0], sob[0]);
+    plan(ft[1], sob[1]);
+    auto prepare = [&](int s1) __attribute__((always_inline)) {       // the copies step s1 reads
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        if (s1 < g * NE || fk[g] >= my_pairs) continue;
+        if (fp[g] < nchunk) {
+          if (ft[g].valid) dma(ft[g], sob[g], fp[g], in_s[g][fcc[g] & 1], w_s[g][fcc[g] & 1], true);
+          ++fcc[g];
+        }
+        if (++fp[g] == PERIOD) {
+          fp[g] = 0;
+          if (++fk[g] < my_pairs) { tile_next(ft[g]); plan(ft[g], sob[g]); }
+        }
+      }
+    };
+    prepare(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");          // P
+#pragma unroll 1
+    for (int s = 0; s < n_total; ++s) {
+      if (li == 0) PL_STAMP(2, s, 0);
+      if (s + 1 < n_total && !((DVPL_ABL & 1) && s > 0)) prepare(s + 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (li == 0) PL_STAMP(2, s, 1);
+      asm volatile("s_barrier" ::: "memory");        // B_s
+    }
+    return;
+  }
+
+  // =========================== MFMA waves ===========================
+  const int g = wave >> 2, yl = (wave >> 1) & 1, mw = wave & 1;
+  const int j = lane & 15, kq = lane >> 4;
+  float* const sk = sk_s[wave];
+  const int a_off = kq * CS + yl * RS + mw * 16 + j;     // this lane's A element (k-step 0, shift 0) inside a brick
+  const int Do = 2 * a.D, Ho = 2 * a.H, Wo = 2 * a.W;
+  const size_t oplane = (size_t)Ho * Wo, ovol = (size_t)Do * oplane;
+  const int nsk = SKIP ? a.Cskip / SKC : 0;
+
+  f32x4 acc[8][NT];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[c][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+
+  // ---- per-tile state ----
+  PLTile cur = tile_first(g);
+  unsigned skv = 0;                                      // this lane's byte offset in a skip DMA piece (channel pair 0)
+  float sc[NT], bi[NT];
+  unsigned loff[NT];
+  bool row_ok = false, lo_ok = false, hi_ok = false;
+  auto tile_setup = [&]() __attribute__((always_inline)) {
+    const int yi = cur.y0 + yl, xi = cur.x0 + mw * 16;
+    row_ok = cur.valid && yi < a.H;
+    lo_ok = row_ok && xi + 4 * kq + 1 < a.W;
+    hi_ok = row_ok && xi + 4 * kq + 3 < a.W;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int co = cur.tcb * COUT + n * 16 + j;
+      sc[n] = sb_s[0][co];
+      bi[n] = sb_s[1][co];
+      loff[n] = (unsigned)(((size_t)co * ovol + 2 * (xi + 4 * kq)) * sizeof(float));
+    }
+    if (SKIP) {
+      // skip tile image: quad Q = (kq >> 1) * 64 + row * 16 + (kq & 1) * 8 + cq  (row = (pz, py), cq = column quad): the 8-byte
+      // A reads of a half wave (two k-lanes x 16 positions) then cover 32 distinct bank pairs.  DMA piece p = kq >> 1, lane = Q % 64.
+      const int row = lane >> 4, kl = (lane >> 3) & 1, cq = lane & 7;
+      const int oz = 2 * cur.z0 + (row >> 1), oy = 2 * yi + (row & 1), ox = 2 * xi + 4 * cq;
+      const bool ok = row_ok && ox < Wo;
+      skv = ok ? (unsigned)(((size_t)kl * ovol + ((size_t)oz * Ho + oy) * Wo + ox) * sizeof(float)) : 0xfffffff0u;
+      if ((DVPL_ABL & 64) && ok) skv &= 0x3fff0u;        // (64: timing only, every skip read inside a small window)
+    }
+  };
+
+  // ---- one chunk of 8 input channels: 27 taps x 2 k-steps x 2 N-tiles, then the redir k-step of this chunk ----
+  auto compute = [&](int c, int buf) __attribute__((always_inline)) {
+    // (the redir code is NOT wrapped in a run-time `c < nsk`: the load of `bw` and the wait for it must lie on ONE path, or
+    // the compiler has to assume a pending load into those registers ever after and puts s_waitcnt vmcnt(0) -- which also
+    // drains the stores -- in front of every later write to them.  A chunk beyond the skip channels copies zeros -- the
+    // range check -- and multiplies them: for the hourglass layers every chunk carries skip channels.)
+    constexpr bool SK = SKIP;
+    const bool has_sk = c < nsk;
+    const float* ib = in_s[g][buf] + a_off;
+    const float* wbp = w_s[g][buf] + lane * 4;
+    float bw[NT];
+    if (SK) {
+      const uint64_t ba = reinterpret_cast<uint64_t>(a.skip + (size_t)cur.b * a.Cskip * ovol);
+      i32x4 rs;
+      rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)ba);
+      rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(ba >> 32));     // stride 0: raw buffer
+      rs[2] = __builtin_amdgcn_readfirstlane((int)((unsigned)a.Cskip * (unsigned)(ovol * sizeof(float))));
+      rs[3] = 0x00020000;
+      const unsigned skl = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)sk);
+#pragma unroll
+      for (int p = 0; p < ((DVPL_ABL & 4) ? 0 : 2); ++p)
+        pl_dma16(rs, skl + p * 1024, has_sk ? skv : 0xfffffff0u,
+                 (DVPL_ABL & 64) ? 0u : (unsigned)(c * SKC + 2 * p) * (unsigned)(ovol * sizeof(float)));
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        bw[n] = a.rw[(size_t)(cur.tcb * COUT + n * 16 + j) * a.Cskip + (has_sk ? c : 0) * SKC + kq];
+    }
+    float av[2][2][2][2];                               // [oz][oy][ox][ks], in the order the taps ask for them
+#pragma unroll
+    for (int oz = 1; oz >= 0; --oz)
+#pragma unroll
+      for (int oy = 1; oy >= 0; --oy)
+#pragma unroll
+        for (int ox = 1; ox >= 0; --ox)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) av[oz][oy][ox][ks] = ib[(oz * IY + oy) * RS + ox + ks * 4 * CS];
+    f32x4 bq[3];
+    bq[0] = *reinterpret_cast<const f32x4*>(wbp);
+    bq[1] = *reinterpret_cast<const f32x4*>(wbp + 256);
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int tap = (kz * 3 + ky) * 3 + kx;
+          const int cls = (pl_par(kz) << 2) | (pl_par(ky) << 1) | pl_par(kx);
+          if (tap + 2 < 27 && !(DVPL_ABL & 16)) bq[(tap + 2) % 3] = *reinterpret_cast<const f32x4*>(wbp + (tap + 2) * 256);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+              acc[cls][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[pl_off(kz)][pl_off(ky)][pl_off(kx)][ks],
+                                                                  bq[tap % 3][ks * NT + n], acc[cls][n], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    if (SK && !(DVPL_ABL & 8)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this chunk's skip tile has landed (it was requested 108 MFMAs ago)
+      const float* skr = sk + ((kq >> 1) * 64 + (kq & 1) * 8 + (j >> 1)) * 4 + (j & 1) * 2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const f32x2 sa = *reinterpret_cast<const f32x2*>(skr + r * 64);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int px = 0; px < 2; ++px)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[(r << 1) | px][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[px], bw[n], acc[(r << 1) | px][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  // ---- half an epilogue: output plane pz = E of this wave's input row: two output rows x two channel halves; the px = 0 / 1
+  // classes interleave along x: 8 consecutive outputs per lane and (row, half) ----
+  const float slope = a.act == DV_ACT_LEAKY ? 0.01f : 1.f;
+  auto epilogue = [&](auto ec) __attribute__((always_inline)) {
+    constexpr int R = decltype(ec)::value;                // output row (pz, py) = (R >> 1, R & 1) of this wave's input row
+    if (!row_ok) return;
+    const size_t bbase = (size_t)cur.b * a.Cout * ovol;
+    {
+      constexpr int r = R;
+      const size_t ro = bbase + (size_t)(2 * cur.z0 + (R >> 1)) * oplane + (size_t)(2 * (cur.y0 + yl) + (R & 1)) * Wo;
+      char* orow = reinterpret_cast<char*>(a.out + ((DVPL_ABL & 32) ? (ro & 0xffff) : ro));   // (32: timing only, every store inside a small window)
+      const char* rrow = reinterpret_cast<const char*>(RES ? a.residual + ro : nullptr);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        f32x4 r0 = (f32x4){0.f, 0.f, 0.f, 0.f}, r1 = r0;
+        if (RES) {
+          if (lo_ok) r0 = *reinterpret_cast<const f32x4*>(rrow + loff[n]);
+          if (hi_ok) r1 = *reinterpret_cast<const f32x4*>(rrow + loff[n] + 16);
+        }
+        const f32x4 e0 = acc[r << 1][n], e1 = acc[(r << 1) | 1][n];
+        f32x4 lo, hi;
+        lo[0] = fmaf(e0[0], sc[n], bi[n]); lo[1] = fmaf(e1[0], sc[n], bi[n]);
+        lo[2] = fmaf(e0[1], sc[n], bi[n]); lo[3] = fmaf(e1[1], sc[n], bi[n]);
+        hi[0] = fmaf(e0[2], sc[n], bi[n]); hi[1] = fmaf(e1[2], sc[n], bi[n]);
+        hi[2] = fmaf(e0[3], sc[n], bi[n]); hi[3] = fmaf(e1[3], sc[n], bi[n]);
+        if (RES) { lo += r0; hi += r1; }
+        if (AM == 0) {                                   // max(v, v * 0): NaN stays NaN
+          lo = __builtin_elementwise_max(lo, lo * 0.f);
+          hi = __builtin_elementwise_max(hi, hi * 0.f);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            lo[e] = AM == 2 ? dv_act(lo[e], DV_ACT_MISH) : fmaxf(lo[e], lo[e] * slope);
+            hi[e] = AM == 2 ? dv_act(hi[e], DV_ACT_MISH) : fmaxf(hi[e], hi[e] * slope);
+          }
+        }
+        const unsigned lo_off = (DVPL_ABL & 32) ? (loff[n] & 0x3ffffu) : loff[n];
+        if (lo_ok && !(DVPL_ABL & 2)) *reinterpret_cast<f32x4*>(orow + lo_off) = lo;
+        if (hi_ok && !(DVPL_ABL & 2)) *reinterpret_cast<f32x4*>(orow + lo_off + 16) = hi;
+      }
+    }
+  };
+
+  zero_acc();
+  int k = 0, p = 0, cc = 0;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // P
+  tile_setup();
+#pragma unroll 1
+  for (int s = 0; s < n_total; ++s) {
+    if ((wave & 3) == 0) PL_STAMP(g, s, 0);
+    if (s >= g * NE && k < my_pairs) {
+      if (p < nchunk) {
+        if (cur.valid && !(DVPL_ABL & 128)) compute(p, cc & 1);
+        ++cc;
+      } else {
+        const int e = p - nchunk;                          // epilogue step e stores rows e * 4 / NE ...
+        if (DVPL_PRIO & 2) __builtin_amdgcn_s_setprio(2);
+        constexpr int RPS = 4 / NE;
+        if (e == 0) {
+          epilogue(std::integral_constant<int, 0>{});
+          if (RPS > 1) epilogue(std::integral_constant<int, 1>{});
+          if (RPS > 2) { epilogue(std::integral_constant<int, 2>{}); epilogue(std::integral_constant<int, 3>{}); }
+        } else if (e == 1) {
+          epilogue(std::integral_constant<int, RPS>{});
+          if (RPS > 1) epilogue(std::integral_constant<int, RPS + 1 < 4 ? RPS + 1 : 3>{});
+        } else if (e == 2) {
+          epilogue(std::integral_constant<int, 2>{});
+        } else {
+          epilogue(std::integral_constant<int, 3>{});
+        }
+      }
+      if (++p == PERIOD) {
+        p = 0;
+        if (++k < my_pairs) { tile_next(cur); tile_setup(); }
+        zero_acc();
+      }
+      if (DVPL_PRIO & 2) __builtin_amdgcn_s_setprio(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if ((wave & 3) == 0) PL_STAMP(g, s, 1);
+    asm volatile("s_barrier" ::: "memory");        // B_s
+  }
+}
+
+}  // namespace
+
+#ifdef DVPL_STAMP
+extern "C" int dv_deconv3d_pl_read_stamps(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pl_stamps), sizeof(g_pl_stamps));
+}
+#endif
+namespace {
+
+inline int pl_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+int pl_cu_count() {
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  static int cache[64] = {0};                            // per device (a DataParallel-style caller has several)
+  if (dev >= 0 && dev < 64 && cache[dev] > 0) return cache[dev];
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+  if (dev >= 0 && dev < 64) cache[dev] = v;
+  return v;
+}
+
+template <bool SKIP, bool RES, int AM>
+int pl_launch(const PLArgs& a, hipStream_t s) {
+  const long long slots = pl_cu_count();
+  const long long pairs = (((long long)a.nsp + 1) / 2) * a.nco;
+  const unsigned blocks = (unsigned)(pairs < slots ? pairs : slots);
+  hipLaunchKernelGGL((deconv3d_pl_kernel<SKIP, RES, AM>), dim3(blocks), dim3(512 + 64 * pl::NL), 0, s, a);
+  return dv_launch_status();
+}
+
+}  // namespace
+
+// shapes the persistent kernel takes (everything else stays on deconv3d_mfma_kernel): whole 8-channel chunks and 32-channel
+// output blocks, rows that travel as 16-byte quads, 32-bit byte offsets inside a batch item, skip channels four per chunk
+extern "C" int dv_deconv3d_pl_supported(int Cin, int Cout, int D, int H, int W, int Cskip) {
+  if (Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0 || Cskip < 0) return 0;
+  if (Cin % pl::KC || Cout % pl::COUT || Cout > pl::MAXCO || W % 4) return 0;
+  if (Cskip % pl::SKC || Cskip / pl::SKC > Cin / pl::KC) return 0;
+  const size_t vol = (size_t)D * H * W;
+  if (vol * sizeof(float) * pl::KC > 0x7fffffffull) return 0;
+  if ((size_t)Cout * 8 * vol * sizeof(float) > 0xffffffffull) return 0;
+  if ((size_t)Cskip * 8 * vol * sizeof(float) > 0xffffffffull) return 0;
+  return 1;
+}
+
+// internal entry (deconv3d.hip routes to it): same packed weights as dv_deconv3d_pack_weights_f32
+int dv_deconv3d_pl_run(const float* in, const float* wpacked, const float* ch_scale, const float* ch_bias, const float* residual,
+                       const float* skip, const float* rw, float* out, int B, int Cin, int D, int H, int W, int Cout, int Cskip,
+                       int act, size_t wpk_floats, hipStream_t s) {
+  PLArgs a;
+  a.in = in; a.wpk = wpacked; a.ch_scale = ch_scale; a.ch_bias = ch_bias; a.residual = residual; a.skip = skip; a.rw = rw;
+  a.out = out; a.B = B; a.Cin = Cin; a.D = D; a.H = H; a.W = W; a.Cout = Cout; a.Cskip = skip ? Cskip : 0; a.act = act;
+  a.ntx = pl_cdiv(W, pl::TW); a.nty = pl_cdiv(H, pl::TH); a.nco = Cout / pl::COUT;
+  const long long tiles = (long long)B * D * a.nty * a.ntx;
+  if (tiles <= 0 || tiles * a.nco > 0x3fffffffLL) return DV_ERR_SHAPE;
+  a.nsp = (int)tiles;
+  if (wpk_floats * sizeof(float) > 0x7fffffffull) return DV_ERR_SHAPE;
+  a.wpk_bytes = (unsigned)(wpk_floats * sizeof(float));
+  const int am = act == DV_ACT_RELU ? 0 : (act == DV_ACT_MISH ? 2 : 1);
+  if (skip) {
+    if (am == 0) return pl_launch<true, false, 0>(a, s);
+    if (am == 2) return pl_launch<true, false, 2>(a, s);
+    return pl_launch<true, false, 1>(a, s);
+  }
+  if (residual) {
+    if (am == 0) return pl_launch<false, true, 0>(a, s);
+    if (am == 2) return pl_launch<false, true, 2>(a, s);
+    return pl_launch<false, true, 1>(a, s);
+  }
+  if (am == 0) return pl_launch<false, false, 0>(a, s);
+  if (am == 2) return pl_launch<false, false, 2>(a, s);
+  return pl_launch<false, false, 1>(a, s);
+}

@@ -168,6 +168,16 @@ int dv_deconv3d_k3s2_f32(const float* in, const float* wpacked, const float* ch_
                          const float* ch_bias, const float* residual, float* out,
                          int B, int Cin, int D, int H, int W, int Cout, int act, dv_stream_t stream);
 
+/* The k3 flavour has two launch shapes behind dv_deconv3d_k3s2_f32 / dv_deconv3d_k3s2_redir_f32 (same packed weights, same
+ * arithmetic per output up to the order in which the fused skip channels join the sum): one-tile blocks
+ * (csrc/deconv3d.hip) and one persistent block per CU with loader waves (csrc/deconv3d_pl.hip).
+ * dv_deconv3d_pl_supported: 1 if the persistent kernel takes the shape (Cskip = 0: no fused skip convolution) -- whole
+ * 8-channel input chunks, 32-channel output blocks, W % 4 == 0, Cskip % 4 == 0 and Cskip / 4 <= Cin / 8, 32-bit byte offsets
+ * inside a batch item; the entry points also want 16-byte aligned tensors for it.  The choice never looks at the batch size.
+ * dv_deconv3d_set_impl (test hook, process-wide): 0 = the launcher picks, 1 = one-tile blocks, 2 = persistent where supported. */
+int dv_deconv3d_pl_supported(int Cin, int Cout, int D, int H, int W, int Cskip);
+int dv_deconv3d_set_impl(int mode);
+
 /* nn.ConvTranspose3d(kernel 4, stride 2, padding 1, bias=False) [+BN +LeakyReLU]: the IGEV hourglass's
  * conv3_up / conv2_up / conv1_up (KITTI15/core/igev_stereo_ddim.py:44-51, BasicConv deconv core/submodule.py:9-35).
  * w [Cin,Cout,4,4,4]; in [B,Cin,D,H,W] -> out [B,Cout,2D,2H,2W]; same fused epilogue as the k3 flavour. */

@@ -64,6 +64,7 @@ SIGNATURES = {
     "dv_deconv3d_k3s2_f32": (c_int, [P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "dv_deconv3d_pl_supported": (c_int, [I, I, I, I, I, I]),
     "dv_deconv3d_set_impl": (c_int, [I]),
+    "dv_deconv3d_pl_set_max_blocks": (c_int, [I]),
     "dv_deconv3d_k4_packed_floats": (c_size_t, [I, I]),
     "dv_deconv3d_k4_pack_weights_f32": (c_int, [P, P, I, I, P]),
     "dv_deconv3d_k4s2_f32": (c_int, [P, P, P, P, P, P, I, I, I, I, I, I, I, P]),

@@ -16,11 +16,16 @@
 //     epilogue's stores leave the CU beside the partner group's MFMA stream by construction instead of by the luck of two
 //     independent blocks' phases, and no tile has a prologue: its first brick is copied during the previous tile's
 //     epilogue.
+#include <atomic>
 #include <type_traits>
 
 #include "dv_common.h"
 
 namespace {
+
+// test hook (dv_deconv3d_pl_set_max_blocks): 0 = one block per CU; n > 0 = at most n blocks, so that small test volumes walk
+// long tile lists (the result does not depend on the grid: every output is summed in the same order by whichever block)
+std::atomic<int> g_pl_max_blocks{0};
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -120,62 +125,51 @@ __global__ __launch_bounds__(512 + 64 * pl::NL, 1) void deconv3d_pl_kernel(PLArg
     sb_s[1][i] = a.ch_bias ? a.ch_bias[i] : 0.f;
   }
 
-  // ---- tile list.  A PAIR = two spatial tiles (x neighbours where the tile count along x is even) x ONE block of 32 output
-  // channels: group g computes spatial tile 2 SP + g.  (Both groups of a block walk the same weight chunks, two steps apart;
-  // one shared ring of four weight images instead of two double buffers -- 27 instead of 54 weight pieces per step -- was
-  // built and measured SLOWER, 1.78 vs 1.70 ms: profiles/r06_deconv_pl_experiments.txt.)  Pairs are ordered output-channel
-  // block fastest, then x, y, z, batch;
-  // every XCD owns a contiguous slab of that order (neighbours share bricks and halos in its L2) and its blocks walk it
-  // round-robin (as conv3d_s2pp.hip). ----
-  const unsigned nblk = gridDim.x, xcd = blockIdx.x & 7u, bidx = blockIdx.x >> 3;
-  const unsigned nbx = (nblk >> 3) + (xcd < (nblk & 7u) ? 1u : 0u);
-  const unsigned npairs = (((unsigned)a.nsp + 1u) >> 1) * (unsigned)a.nco;
-  const unsigned tq = npairs >> 3, trm = npairs & 7u;
+  // ---- tile list (as conv3d_s2pp.hip): tiles in the order output-channel block fastest, then x, y, z, batch; tiles 2 P and
+  // 2 P + 1 are PAIR P (the two channel blocks of one brick where the layer has an even number of them, else x neighbours):
+  // group g of a block computes tile 2 P + g.  Every XCD owns a contiguous slab of the pair order -- neighbours share
+  // bricks, halos and skip rows in its L2 -- and its blocks walk it round-robin.  (A launch of fewer than 8 blocks, which
+  // only the test hook produces, has that many slabs instead of 8.) ----
+  const unsigned nblk = gridDim.x, nx = nblk < 8u ? nblk : 8u, xcd = blockIdx.x % nx, bidx = blockIdx.x / nx;
+  const unsigned nbx = nblk / nx + (xcd < nblk % nx ? 1u : 0u);
+  const unsigned ntiles_ = (unsigned)a.nsp * (unsigned)a.nco;
+  const unsigned npairs = (ntiles_ + 1u) >> 1;
+  const unsigned tq = npairs / nx, trm = npairs % nx;
   const unsigned slab_lo = xcd < trm ? xcd * (tq + 1) : trm * (tq + 1) + (xcd - trm) * tq;
   const unsigned slab_n = tq + (xcd < trm ? 1u : 0u);
   const int my_pairs = __builtin_amdgcn_readfirstlane(bidx < slab_n ? (int)((slab_n - bidx + nbx - 1) / nbx) : 0);
   if (my_pairs == 0) return;
-  // the block's pairs are nbx apart: the first one is decoded by division, the later ones by adding the stride's digits with
-  // carries (scalar adds and compares; the divisions would be vector-ALU work beside the partner group's MFMA stream)
+  // a group's tiles are 2 * nbx apart in the linear order: the first one is decoded by division, the later ones by adding the
+  // stride's digits with carries (scalar adds and compares instead of five divisions per tile)
   auto rfl = [](unsigned v) __attribute__((always_inline)) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
-  auto decode = [&](unsigned st, int (&d)[4]) __attribute__((always_inline)) {       // spatial tile -> x, y, z, batch
-    d[0] = (int)rfl(st % a.ntx); st /= a.ntx;
-    d[1] = (int)rfl(st % a.nty); st /= a.nty;
-    d[2] = (int)rfl(st % a.D);
-    d[3] = (int)rfl(st / a.D);
+  auto decode = [&](unsigned t, int (&d)[5]) __attribute__((always_inline)) {
+    d[0] = (int)rfl(t % a.nco); t /= a.nco;
+    d[1] = (int)rfl(t % a.ntx); t /= a.ntx;
+    d[2] = (int)rfl(t % a.nty); t /= a.nty;
+    d[3] = (int)rfl(t % a.D);
+    d[4] = (int)rfl(t / a.D);
   };
-  const int s_tc = (int)rfl(nbx % (unsigned)a.nco);
-  int sd[4];
-  decode(2u * (nbx / (unsigned)a.nco), sd);
+  int sd[5];
+  decode(2u * nbx, sd);
   auto tile_first = [&](int g) __attribute__((always_inline)) {
     PLTile r;
-    const unsigned P = slab_lo + bidx;
-    r.tcb = (int)rfl(P % (unsigned)a.nco);
-    r.st = rfl(2u * (P / (unsigned)a.nco) + (unsigned)g);
-    r.valid = r.st < (unsigned)a.nsp;
-    int d[4];
-    decode(r.valid ? r.st : (unsigned)a.nsp - 1u, d);
-    r.xi = d[0]; r.yi = d[1]; r.z0 = d[2]; r.b = d[3];
+    r.st = 2u * (slab_lo + bidx) + (unsigned)g;
+    r.valid = r.st < ntiles_;
+    int d[5];
+    decode(r.valid ? r.st : ntiles_ - 1u, d);
+    r.tcb = d[0]; r.xi = d[1]; r.yi = d[2]; r.z0 = d[3]; r.b = d[4];
     r.x0 = r.xi * TW; r.y0 = r.yi * TH;
     return r;
   };
   auto tile_next = [&](PLTile& r) __attribute__((always_inline)) {
-    r.tcb += s_tc;
-    const int c0 = r.tcb >= a.nco ? 1 : 0;
-    r.tcb -= c0 ? a.nco : 0;
-    r.st += 2u * (nbx / (unsigned)a.nco) + 2u * (unsigned)c0;
-    r.valid = r.st < (unsigned)a.nsp;                    // (past the end the digits are never used)
+    r.st += 2u * nbx;
+    r.valid = r.st < ntiles_;
     int c;
-    r.xi += sd[0] + 2 * c0; c = 0;
-    if (r.xi >= a.ntx) { r.xi -= a.ntx; c = 1; }
-    if (r.xi >= a.ntx) { r.xi -= a.ntx; c = 2; }
-    r.yi += sd[1] + c; c = 0;
-    if (r.yi >= a.nty) { r.yi -= a.nty; c = 1; }
-    if (r.yi >= a.nty) { r.yi -= a.nty; c = 2; }
-    r.z0 += sd[2] + c; c = 0;
-    if (r.z0 >= a.D) { r.z0 -= a.D; c = 1; }
-    if (r.z0 >= a.D) { r.z0 -= a.D; c = 2; }
-    r.b += sd[3] + c;
+    r.tcb += sd[0];      c = r.tcb >= a.nco; r.tcb -= c ? a.nco : 0;
+    r.xi += sd[1] + c;   c = r.xi >= a.ntx;  r.xi -= c ? a.ntx : 0;
+    r.yi += sd[2] + c;   c = r.yi >= a.nty;  r.yi -= c ? a.nty : 0;
+    r.z0 += sd[3] + c;   c = r.z0 >= a.D;    r.z0 -= c ? a.D : 0;
+    r.b += sd[4] + c;
     r.x0 = r.xi * TW; r.y0 = r.yi * TH;
   };
 
@@ -489,14 +483,21 @@ int pl_cu_count() {
 
 template <bool SKIP, bool RES, int AM>
 int pl_launch(const PLArgs& a, hipStream_t s) {
-  const long long slots = pl_cu_count();
-  const long long pairs = (((long long)a.nsp + 1) / 2) * a.nco;
+  const int cap = g_pl_max_blocks.load(std::memory_order_relaxed);
+  const long long slots = cap > 0 ? cap : pl_cu_count();
+  const long long pairs = ((long long)a.nsp * a.nco + 1) / 2;
   const unsigned blocks = (unsigned)(pairs < slots ? pairs : slots);
   hipLaunchKernelGGL((deconv3d_pl_kernel<SKIP, RES, AM>), dim3(blocks), dim3(512 + 64 * pl::NL), 0, s, a);
   return dv_launch_status();
 }
 
 }  // namespace
+
+extern "C" int dv_deconv3d_pl_set_max_blocks(int n) {
+  DV_REQUIRE(n >= 0, DV_ERR_SHAPE);
+  g_pl_max_blocks.store(n, std::memory_order_relaxed);
+  return DV_OK;
+}
 
 // shapes the persistent kernel takes (everything else stays on deconv3d_mfma_kernel): whole 8-channel chunks and 32-channel
 // output blocks, rows that travel as 16-byte quads, 32-bit byte offsets inside a batch item, skip channels four per chunk

@@ -177,6 +177,9 @@ int dv_deconv3d_k3s2_f32(const float* in, const float* wpacked, const float* ch_
  * dv_deconv3d_set_impl (test hook, process-wide): 0 = the launcher picks, 1 = one-tile blocks, 2 = persistent where supported. */
 int dv_deconv3d_pl_supported(int Cin, int Cout, int D, int H, int W, int Cskip);
 int dv_deconv3d_set_impl(int mode);
+/* Test hook, process-wide: the persistent kernel launches at most n blocks (0 = one per CU), so that small volumes exercise
+ * long per-block tile lists; results do not depend on it. */
+int dv_deconv3d_pl_set_max_blocks(int n);
 
 /* nn.ConvTranspose3d(kernel 4, stride 2, padding 1, bias=False) [+BN +LeakyReLU]: the IGEV hourglass's
  * conv3_up / conv2_up / conv1_up (KITTI15/core/igev_stereo_ddim.py:44-51, BasicConv deconv core/submodule.py:9-35).

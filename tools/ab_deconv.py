@@ -61,8 +61,21 @@ def check(b, cin, cout, dims, mode="plain", cskip=None, act=S.ACT_RELU):
         y = plan(x, **kw)
         torch.cuda.synchronize()
         errs.append((y.double() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30))
+    same = True
+    for cap in (1, 3, 8, 13):                      # few blocks: long tile lists per block; the bits must not change
+        lib.dv_deconv3d_pl_set_max_blocks(cap)
+        poison = torch.full_like(y, float("nan")); del poison        # the next output lands on these bytes
+        yc = plan(x, **kw)
+        if not torch.equal(yc, y):
+            same = False
+            d = (yc - y).abs()
+            nz = (d > 0).nonzero()
+            print(f"   cap {cap}: max abs diff {d.max().item():.3e} at {d.argmax().item()}, {len(nz)} elements differ of {d.numel()}, first {nz[0].tolist()} last {nz[-1].tolist()}", flush=True)
+    lib.dv_deconv3d_pl_set_max_blocks(0)
     lib.dv_deconv3d_set_impl(0)
-    ok = max(errs) < 1e-5
+    ok = max(errs) < 1e-5 and same
+    if not same:
+        print("   grid-size dependence!", flush=True)
     print(f"B{b} {cin}->{cout} {dims} {mode} cskip={cskip} act={act} pl_supported={sup}: rel err one-tile {errs[0]:.2e} persistent {errs[1]:.2e} "
           f"{'ok' if ok else 'FAIL'}", flush=True)
     return ok
@@ -117,6 +130,9 @@ if "--time" in sys.argv:
             plan = S.Deconv3dPlan(w, bn, act=S.ACT_RELU)
             run = lambda: plan(x)
             fl = 2.0 * x.numel() * cout * 27
+        lib.dv_deconv3d_set_impl(1); y1 = run(); lib.dv_deconv3d_set_impl(2); y2 = run()
+        print(f"   {name}: persistent vs one-tile max rel diff {((y1 - y2).abs().max() / y1.abs().max()).item():.2e}", flush=True)
+        del y1, y2
         out = []
         for r in range(reps):
             for impl in (1, 2):

@@ -49,7 +49,8 @@ S2PP_MULT_REDUCTION = 1.44        # polyphase F(2,2) stride-2 form: 25 instead o
 # the next kernels by time: (KernelTimer tags, rocprofv3 kernel name, issued-flop divisor).  The 64- and 128-channel
 # layers run the 4 x 4- and 8 x 2-tile instantiations of the same template (120- and 60-wide planes, no padding).
 SIDE_KERNELS = [
-    (("deconv3d_k3s2_redir",), "deconv3d_mfma_kernel<3, 8>", 1.0),
+    # transposed convolution + fused redir (round 6): persistent, 8 MFMA waves in two groups + 4 loader waves per CU
+    (("deconv3d_k3s2_redir",), "deconv3d_pl_kernel<true, false, 0>", 1.0),
     # stride 2 (round 5): the polyphase minimal-filtering kernel, 8 x 8-output patches, persistent with loader waves; it
     # issues 1.44 x fewer multiplies than the direct count (25 instead of 36 per 2 x 2 outputs and depth tap)
     (("conv3d_k3s2_co64", "conv3d_k3s2_co128"), "conv3d_s2pp_kernel<1>", S2PP_MULT_REDUCTION),

@@ -49,6 +49,7 @@ SIGNATURES = {
     "dv_conv3d_pack_weights_f32": (c_int, [P, P, I, I, I, P]),
     "dv_conv3d_f32": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "dv_conv3d_set_s2_tile": (c_int, [I]),
+    "dv_conv3d_set_c1z": (c_int, [I, I]),
     "dv_conv3d_f16x3_packed_bytes": (c_size_t, [I, I]),
     "dv_conv3d_f16x3_pack_weights": (c_int, [P, P, I, I, P]),
     "dv_conv3d_f16x3_f32": (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),

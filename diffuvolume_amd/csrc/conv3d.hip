@@ -26,6 +26,10 @@ namespace {
 
 // test hook: 0 = the launcher picks the stride-2 tiling, 1 = 2 x 4 x 32 tiles, 2 = 2 x 2 x 32 tiles (dv_conv3d_set_s2_tile)
 std::atomic<int> g_s2_tile_pin{0};
+// test hook (dv_conv3d_set_c1z): threshold of the z-marching single-channel head in tiles per batch item (default 64) and
+// a pinned segment length (0 = the launcher's choice; 3 / 6 / 12)
+std::atomic<long long> g_c1z_min_tiles{64};
+std::atomic<int> g_c1z_pin_zs{0};
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -656,15 +660,14 @@ int launch_c1z(ConvArgs a, hipStream_t s) {
 }
 
 int launch_c1(ConvArgs a, hipStream_t s) {
-#ifndef DV_C1_BRICK
   // Plain inputs march along z (one fetch per voxel and segment); the filter prologue and small volumes keep the brick
   // kernel.  WHICH kernel runs must not depend on the batch size -- the two add in different orders, and a shard of a
   // batch has to produce the bits the whole batch produces (tests/test_gpu_fullsize.py, the multi-GPU sharding) -- so the
   // choice looks at one batch item only.  The segment length may follow the batch: every output is summed plane by
   // plane, channel by channel whatever segment it lies in, so ZS changes the block count and not a single bit.
-  // DV_C1Z_MIN_BLOCKS / DV_C1Z_ZS (tests) move the threshold / pin the segment length.
-  static const long long min_pp = getenv("DV_C1Z_MIN_BLOCKS") ? atoll(getenv("DV_C1Z_MIN_BLOCKS")) : 64;
-  static const int pin_zs = getenv("DV_C1Z_ZS") ? atoi(getenv("DV_C1Z_ZS")) : 0;
+  // dv_conv3d_set_c1z (tests) moves the threshold / pins the segment length.
+  const long long min_pp = g_c1z_min_tiles.load(std::memory_order_relaxed);
+  const int pin_zs = g_c1z_pin_zs.load(std::memory_order_relaxed);
   const long long tiles = (long long)((a.Ho + c1z::TY - 1) / c1z::TY) * ((a.Wo + c1z::TX - 1) / c1z::TX);
   auto blocks_at = [&](int zs) { return (long long)a.B * ((a.Do + zs - 1) / zs) * tiles; };
   if (!a.in_scale && a.Cin <= c1z::WMAXC && ((a.Do + 2) / 3) * tiles >= min_pp) {
@@ -673,7 +676,6 @@ int launch_c1(ConvArgs a, hipStream_t s) {
     if (zs >= 6) return launch_c1z<6>(a, s);
     return launch_c1z<3>(a, s);
   }
-#endif
   a.ntx = (a.Wo + c1::TX - 1) / c1::TX;
   a.nty = (a.Ho + c1::TY - 1) / c1::TY;
   a.ntz = (a.Do + c1::TZ - 1) / c1::TZ;
@@ -732,6 +734,13 @@ int launch_conv(ConvArgs a, hipStream_t s) {
 extern "C" int dv_conv3d_set_s2_tile(int mode) {
   if (mode < 0 || mode > 2) return DV_ERR_UNSUPPORTED;
   g_s2_tile_pin.store(mode, std::memory_order_relaxed);
+  return DV_OK;
+}
+
+extern "C" int dv_conv3d_set_c1z(int min_tiles, int segment) {
+  if (min_tiles < 0 || (segment != 0 && segment != 3 && segment != 6 && segment != 12)) return DV_ERR_UNSUPPORTED;
+  g_c1z_min_tiles.store(min_tiles > 0 ? min_tiles : 64, std::memory_order_relaxed);
+  g_c1z_pin_zs.store(segment, std::memory_order_relaxed);
   return DV_OK;
 }
 

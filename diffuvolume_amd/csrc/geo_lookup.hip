@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void geo_lookup_kernel(const float* __restrict
   const int dlo = 2 * (int)floorf(d * 0.5f) - 10;
   float* gw = gwin + tid;                               // entry k at gw[k * 256]
   float* nw = nwin + tid;
-  if ((D & 3) == 0) {
+  if ((D & 3) == 0 && ((reinterpret_cast<uintptr_t>(noisy) & 15u) == 0)) {   // (uniform: an offset view of the noise takes the per-float loop)
     // the pixel's noise window is 96 contiguous bytes of its own row: seven aligned 16-byte loads (dlo is even, the row
     // starts on a 16-byte boundary when D % 4 == 0) instead of 24 single floats -- every one of them a different cache
     // line per lane

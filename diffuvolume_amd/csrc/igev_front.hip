@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256) void conv2d_fewin_kernel(const float* __restri
 // One block of 1024 threads per (b, c) plane.  Pass 1: sum -> mean; pass 2: sum of squared deviations -> biased variance
 // (the two-pass form: no cancellation); pass 3: normalise + activation.  Per-thread partial sums run over a fixed stride
 // and are combined by a fixed tree, so the result depends on nothing but the plane.
-__global__ __launch_bounds__(1024) void instance_norm_act_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                                 int HW, float eps, int act) {
+// (`in` and `out` may be the same tensor -- the wrapper's default is in place --, so neither is __restrict__)
+__global__ __launch_bounds__(1024) void instance_norm_act_kernel(const float* in, float* out, int HW, float eps, int act) {
   __shared__ float red[16];
   __shared__ float stat;
   const size_t base = (size_t)blockIdx.x * HW;

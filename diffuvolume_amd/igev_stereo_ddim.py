@@ -353,7 +353,6 @@ def instance_norm_act(x: torch.Tensor, act: int = ACT_NONE, eps: float = 1e-5, i
     return out
 
 
-_ACT_OF = {nn.ReLU: ACT_RELU, nn.LeakyReLU: ACT_LEAKY}
 
 
 def hip_sequential(seq, x: torch.Tensor) -> torch.Tensor:
@@ -376,7 +375,8 @@ def hip_sequential(seq, x: torch.Tensor) -> torch.Tensor:
                 a = mods[j]
                 if isinstance(a, nn.LeakyReLU) and abs(a.negative_slope - 0.01) > 1e-12:
                     raise _lib.DiffuVolumeError("LeakyReLU on the HIP front: negative_slope 0.01")
-                act, clamp6, j = (ACT_RELU if isinstance(a, nn.ReLU6) else _ACT_OF[type(a)]), isinstance(a, nn.ReLU6), j + 1
+                act = ACT_LEAKY if isinstance(a, nn.LeakyReLU) else ACT_RELU            # (isinstance: subclasses of the three too)
+                clamp6, j = isinstance(a, nn.ReLU6), j + 1
             if inorm is not None:
                 x = instance_norm_act(hip_conv2d(m, x), act, inorm.eps)
             else:

@@ -115,6 +115,10 @@ int dv_conv3d_f32(const float* in, const float* wpacked, const float* ch_scale, 
 /* Test hook: pins the tiling of the DIRECT stride-2 kernel (0 = the launcher's own choice from the size of one batch item,
  * 1 = 2 x 4 x 32 output tiles, 2 = 2 x 2 x 32); both tilings give the same bits.  Process-wide; returns DV_OK. */
 int dv_conv3d_set_s2_tile(int mode);
+/* Test hook, process-wide: the z-marching form of the single-output-channel head (conv3d_c1z_kernel) takes volumes of at
+ * least `min_tiles` 16 x 64 tiles per batch item (0 = the default, 64); `segment` pins the planes per block (0 = the
+ * launcher's choice from the block count; 3, 6 or 12 -- every segment length gives the same bits). */
+int dv_conv3d_set_c1z(int min_tiles, int segment);
 
 /* The same 3x3x3 stride-1 layer (Cout <= 32) on the fp16 matrix instruction with every fp32 operand
  * carried as hi+lo fp16 pairs: x*w ~= hi*hi' + hi*lo' + lo*hi', fp32 accumulate (csrc/conv3d_f16x3.hip).
@@ -148,7 +152,7 @@ int dv_conv3d_wino_f32(const float* in, const float* wpacked, const float* ch_sc
  *   y = act( conv_s2(in) * ch_scale[co] + ch_bias[co] + residual )
  * 64 output channels per block and rows that travel as 16-byte quads: dv_conv3d_s2pp_supported says whether a layer
  * qualifies (Cout a multiple of 64, W a multiple of 4, D*H*W*4 <= 2^30; `in` 16-byte aligned), dv_conv3d_s2pp_f32 returns
- * DV_ERR_UNSUPPORTED otherwise.  Persistent launch: two blocks per CU walk the tile list.
+ * DV_ERR_UNSUPPORTED otherwise.  Persistent launch: one persistent block per CU, two tiles at a time.
  * `wpacked` from dv_conv3d_s2pp_pack_weights_f32. */
 int dv_conv3d_s2pp_supported(int Cin, int Cout, int D, int H, int W);
 size_t dv_conv3d_s2pp_packed_floats(int Cin, int Cout);

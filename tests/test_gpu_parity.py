@@ -1068,44 +1068,37 @@ def test_precision_switch_selects_kernels(monkeypatch):
 
 def test_conv_single_channel_head_z_march():
     """The z-marching form of the Cout == 1 head (csrc/conv3d.hip, conv3d_c1z_kernel: a 16 x 64 tile, a segment of 3 / 6 / 12
-    output planes per block, three rotating accumulator sets) takes over for volumes of >= 64 tiles per batch item; here
-    DV_C1Z_MIN_BLOCKS=1 forces it (read once per process, hence the child processes) onto ragged shapes: depth that is not
-    a multiple of the segment, several segments, partial tiles in y and x, unaligned rows, channel counts 1 .. 33,
-    residual + ReLU.  The segment length follows the batch size (block count) in production, so it must not change a
-    single bit: the three pinned lengths have to agree exactly -- that is what keeps a shard of a batch bit-identical to
-    the batch (tests/test_gpu_fullsize.py) although the launches differ."""
-    import os
-    import subprocess
-    import sys
-    code = r'''
-import sys, hashlib, torch
-sys.path.insert(0, %r)
-from diffuvolume_amd import submodule as S
-from diffuvolume_amd.synth import _gen
-h = hashlib.sha256()
-for cin, dims, extras in [(5, (1, 3, 5, 7), False), (33, (2, 13, 9, 70), True), (32, (1, 25, 18, 130), False),
-                          (1, (1, 1, 1, 1), False), (32, (1, 12, 16, 64), True), (7, (1, 27, 33, 67), True)]:
-    g = _gen(29, str((cin, dims)))
-    x = torch.randn(dims[0], cin, *dims[1:], generator=g)
-    w = torch.randn(1, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5
-    res = torch.randn(dims[0], 1, *dims[1:], generator=g) if extras else None
-    y = torch.nn.functional.conv3d(x.double(), w.double(), None, 1, 1)
-    if res is not None:
-        y = torch.relu(y + res.double())
-    plan = S.Conv3dPlan(w.cuda(), None, stride=1, act=S.ACT_RELU if extras else S.ACT_NONE)
-    out = plan(x.cuda(), residual=None if res is None else res.cuda())
-    err = float((out.cpu().double() - y).abs().max())
-    assert out.shape == y.shape and err <= 1e-5 * max(1.0, float(y.abs().max())), (cin, dims, err)
-    h.update(out.cpu().numpy().tobytes())
-print("OK", h.hexdigest())
-''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    digests = []
-    for zs in ("3", "6", "12"):
-        env = dict(os.environ, DV_C1Z_MIN_BLOCKS="1", DV_C1Z_ZS=zs)
-        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-        digests.append(r.stdout.split("OK")[-1].strip())
-    assert digests[0] == digests[1] == digests[2], digests
+    output planes per block, three rotating accumulator sets) takes over for volumes of >= 64 tiles per batch item; here the
+    test hook dv_conv3d_set_c1z forces it onto ragged shapes: depth that is not a multiple of the segment, several segments,
+    partial tiles in y and x, unaligned rows, channel counts 1 .. 33, residual + ReLU.  The segment length follows the batch
+    size (block count) in production, so it must not change a single bit: the three pinned lengths have to agree exactly --
+    that is what keeps a shard of a batch bit-identical to the batch (tests/test_gpu_fullsize.py) although the launches
+    differ."""
+    from diffuvolume_amd import _lib
+    lib = _lib.load()
+    outs = {}
+    try:
+        for zs in (3, 6, 12):
+            assert lib.dv_conv3d_set_c1z(1, zs) == 0
+            for cin, dims, extras in [(5, (1, 3, 5, 7), False), (33, (2, 13, 9, 70), True), (32, (1, 25, 18, 130), False),
+                                      (1, (1, 1, 1, 1), False), (32, (1, 12, 16, 64), True), (7, (1, 27, 33, 67), True)]:
+                g = _gen(29, str((cin, dims)))
+                x = torch.randn(dims[0], cin, *dims[1:], generator=g)
+                w = torch.randn(1, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5
+                res = torch.randn(dims[0], 1, *dims[1:], generator=g) if extras else None
+                y = torch.nn.functional.conv3d(x.double(), w.double(), None, 1, 1)
+                if res is not None:
+                    y = torch.relu(y + res.double())
+                plan = S.Conv3dPlan(dev(w), None, stride=1, act=S.ACT_RELU if extras else S.ACT_NONE)
+                out = plan(dev(x), residual=None if res is None else dev(res))
+                err = float((out.cpu().double() - y).abs().max())
+                assert out.shape == y.shape and err <= 1e-5 * max(1.0, float(y.abs().max())), (cin, dims, err)
+                outs.setdefault((cin, dims), []).append(out.cpu())
+        assert lib.dv_conv3d_set_c1z(1, 5) != 0
+    finally:
+        lib.dv_conv3d_set_c1z(0, 0)
+    for key, o in outs.items():
+        assert torch.equal(o[0], o[1]) and torch.equal(o[0], o[2]), key
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 128, 8, 12, 60), (1, 32, 64, 6, 9, 37), (1, 16, 64, 4, 8, 64)])

@@ -190,3 +190,24 @@ def test_rendezvous_port_below_the_ephemeral_range():
     assert all(20000 <= p < 30000 for p in ports)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", next(iter(ports))))          # still free
+
+
+def test_one_place_for_switches(monkeypatch):
+    """The native library reads no environment variable (kernel choices are pinned through dv_*_set_* hooks), and every
+    DV_* variable the Python side reads is listed in diffuvolume_amd/_env.py -- the list bench.py reports overrides from."""
+    import re
+    from pathlib import Path
+    from diffuvolume_amd import _env
+    root = Path(__file__).resolve().parents[1]
+    for f in (root / "diffuvolume_amd" / "csrc").glob("*.hip"):
+        assert "getenv" not in f.read_text(), f.name
+    read = set()
+    for f in list((root / "diffuvolume_amd").glob("*.py")) + [root / "bench.py"]:
+        read |= set(re.findall(r"environ(?:\.get|\.setdefault)?\(\s*[\"'](DV_[A-Z0-9_]+)[\"']", f.read_text()))
+        read |= set(re.findall(r"environ\[\s*[\"'](DV_[A-Z0-9_]+)[\"']\s*\]", f.read_text()))
+    assert read <= set(_env.KNOBS), read - set(_env.KNOBS)
+    for k in _env.KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    assert _env.overrides() == {}
+    monkeypatch.setenv("DV_S2PP", "0")
+    assert _env.overrides() == {"DV_S2PP": "0"}

@@ -448,6 +448,25 @@ def extras(a, sd, x, mask, device):
         dt = timed_loop(test_sample, 2)
         res["end_to_end_test_sample"] = {"value": a.batch / dt, "unit": "pairs/s", "ms_per_batch": 1e3 * dt,
                                          "note": "origin ACVNet + feature CNNs + attention branch + hot path + metrics, all on the HIP kernels"}
+        # the same at batch 1: per-pair LATENCY, the way the reference evaluates (test_sceneflow_ddim.py:39,:48,:73-82) and
+        # the only kind of number it publishes
+        left, right = left[:1].contiguous(), right[:1].contiguous()
+        gt1, mask1 = x["gt"][:1].contiguous(), mask[:1].contiguous()
+
+        def test_sample_b1():
+            used = origin(left, right)[-1]
+            dn = torch.clamp(used, 0, 191).unsqueeze(1)
+            dn = torch.nn.functional.interpolate(dn, size=(a.height // 4, a.width // 4), mode="bilinear") / 4
+            pred = ddim(left, right, used, dn, None)[0]
+            return M.batch_metrics(pred, gt1, mask1)
+
+        dt1 = timed_loop(test_sample_b1, 3)
+        res["latency_b1_test_sample"] = {
+            "ms_per_pair": 1e3 * dt1, "batch": 1, "frame": f"{a.width}x{a.height}",
+            "what": "origin ACVNet + ACVNet_DDIM.forward (features, attention branch, 5 DDIM steps) + metrics, one pair",
+            "reference_readme_s_per_pair": 1.11,
+            "reference_note": "README.md:108 (SceneFlow table, Runtime) quotes 1.11 s per pair for DiffuVolume on unspecified hardware: context, "
+                              "not a baseline (never vs_baseline)"}
         del origin, ddim
     # (3) BASELINE configs 4 and 5 on one GPU (parity cases, not the headline): hot-path speed, dominant kernel and its
     # issued fraction of the fp32 matrix pipe -- a few seconds each
@@ -472,6 +491,14 @@ def extras(a, sd, x, mask, device):
                           "forward, batch 4 on one GPU)", "forward_ms": r5["forward_ms"],
                           "ms_per_gru_iteration": r5["ms_per_gru_iteration"],
                           "dominant_kernel": dominant(r5["kernels_of_a_2_iteration_pass"])}
+        torch.cuda.empty_cache()
+        rd = BF.igev_reference_default(b=1)
+        res["latency_b1_kitti15_reference_default"] = {
+            "ms_per_pair": rd["ms_per_pair"], "batch": 1, "workload": rd["config"],
+            "reference_readme_s_per_pair": 0.18,
+            "reference_note": "README.md:98 (KITTI 2015 leaderboard, Runtime) quotes 0.18 s per pair for IGEV+DiffuVolume on unspecified hardware; the reference "
+                              "hard-codes 2 DDIM steps (core/igev_stereo_ddim.py:124), BASELINE config 5 names 20: context, "
+                              "not a baseline"}
     except Exception as e:                               # noqa: BLE001 -- a side measurement must not sink the bench line
         res["config4_5_error"] = f"{type(e).__name__}: {e}"[:300]
     return res

@@ -174,6 +174,39 @@ def igev_model(b=4, h=384, w=1248, steps=20, iters=32, quick=False):
             "forward_ms": ms, "pairs_per_s": b / (ms / 1e3), "ms_per_gru_iteration": ms / (steps * iters)}
 
 
+def igev_reference_default(b=1, h=384, w=1248, iters=32):
+    """KITTI15 the way the reference evaluates it (KITTI15/evaluate_stereo.py:88-129): the origin IGEVStereo forward, its
+    disparity down-sampled to 1/4, then IGEVStereo_ddim at the reference's own hard-coded 2 DDIM steps
+    (core/igev_stereo_ddim.py:124), `iters` GRU iterations each, batch b (the reference: 1).  Stub MobileNetV2 backbone."""
+    import types
+    import torch.nn.functional as F
+    from diffuvolume_amd.igev_stereo import IGEVStereo
+    from diffuvolume_amd.igev_stereo_ddim import Feature, IGEVStereo_ddim
+    from diffuvolume_amd.synth import StubMobileNetV2
+    args = types.SimpleNamespace(hidden_dims=[128, 128, 128], n_gru_layers=3, n_downsample=2, corr_levels=2, corr_radius=4,
+                                 slow_fast_gru=False, max_disp=192, mixed_precision=False)
+    sc = {"update_block.disp_head.conv2.weight": 0.05, "update_block.disp_head.conv2.bias": 0.0, "classifier.weight": 20.0}
+    m = IGEVStereo_ddim(args, feature=Feature(StubMobileNetV2()))
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed=7, scale=sc), strict=True)
+    m = m.to(DEV).eval()
+    o = IGEVStereo(args, feature=Feature(StubMobileNetV2()))
+    o.load_state_dict(synth_state_dict(o.state_dict(), seed=8, scale=sc), strict=True)
+    o = o.to(DEV).eval()
+    g = _gen(77, "cfg5")
+    img1 = (torch.rand(b, 3, h, w, generator=g) * 255).to(DEV)
+    img2 = torch.roll(img1, -9, dims=-1)
+
+    def both():
+        flow_pr = o(img1, img2, iters=iters, test_mode=True)
+        flow_4 = F.interpolate(torch.clamp(flow_pr, 0, w - 1), size=(h // 4, w // 4), mode="bilinear") / 4
+        return m(img1, img2, flow_pr, flow_4, iters=iters, test_mode=True)
+
+    with torch.no_grad():
+        ms = timeit(both, warmup=1, steps=3)
+    return {"config": f"KITTI15 origin IGEVStereo + IGEVStereo_ddim (2 DDIM steps x {iters} GRU iterations) B={b} {w}x{h} (stub backbone)",
+            "ms_per_pair": ms / b, "ms_per_batch": ms, "batch": b}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pcw", action="store_true")

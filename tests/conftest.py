@@ -12,6 +12,11 @@ if str(ROOT) not in sys.path:
 
 GOLDEN = ROOT / "tests" / "golden"
 
+# torch's own GPU convolutions (MIOpen) appear in the GPU suite only as REFERENCES for a handful of full-size property tests:
+# its exhaustive solver search costs tens of seconds per new shape, the fast find mode a fraction of that (set before MIOpen
+# is initialised; the product path never calls MIOpen)
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -649,6 +649,8 @@ def test_conv_f16x3_oracle(cfg):
     assert e16 < 3 * e32 + 1e-7, (e16, e32)      # as close to float64 as the exact-fp32 MFMA kernel
 
 
+@pytest.mark.skipif(__import__("os").environ.get("DV_FULL_PARITY") != "1",
+                    reason="the opt-in split-fp16 path (not the contract's arithmetic; its layer test above stays): DV_FULL_PARITY=1")
 def test_ddim_loop_with_split_fp16_convs(acv_state_dict):
     """The whole 5-step loop with the 3x3x3 stride-1 convs on the split-fp16 MFMA kernel: same bars as
     the exact-fp32 build (median within 1e-4 px of the reference, distance to float64 comparable)."""

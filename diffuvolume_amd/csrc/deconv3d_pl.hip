@@ -67,8 +67,10 @@ static_assert((2 * 2 * (W_FLOATS + BRICK_FLOATS) + 8 * SK_FLOATS + 2 * MAXCO) * 
 // the top of every chunk) nor a draining fence at the barrier; the one wait this copy needs is written out where the tile is
 // read.  (Untracked OLDER operations only make the compiler's own counted waits wait longer than it thinks: in-order counter.)
 __device__ __forceinline__ void pl_dma16(i32x4 rsrc, unsigned lds, unsigned voff, unsigned soff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-               :: "s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  unsigned m0_saved;             // M0 is reserved by the compiler: hand it back as found (as conv3d_wino.hip does)
+  // (s_nop 0: one wait state between a scalar write of M0 and the LDS-DMA that reads it; tests/test_isa_lint.py)
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(m0_saved) : "s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 
 __host__ __device__ constexpr int pl_par(int k) { return (k + 1) & 1; }

@@ -194,10 +194,7 @@ def _dump(name, report):
     print(json.dumps(report))
 
 
-@pytest.mark.parametrize("pair", [pytest.param(0, marks=pytest.mark.skipif(not FULL_PARITY, reason=(
-    "the default (random BatchNorm buffers) network is a recorded diagnostic: bench.py's parity leg prints this very comparison for "
-    "pair 0 in every driver run (`parity_vs_oracle`), the suite holds the contract's bars on the calibrated network below: DV_FULL_PARITY=1"))),
-    pytest.param(2, marks=pytest.mark.skipif(not FULL_PARITY, reason="second full-size pair: DV_FULL_PARITY=1"))])
+@pytest.mark.parametrize("pair", [0, pytest.param(2, marks=pytest.mark.skipif(not FULL_PARITY, reason="second full-size pair: DV_FULL_PARITY=1"))])
 def test_fullsize_oracle_5step(pair):
     """Pairs 0 and 2 of the bench workload (disparity ridge at 6 / 60 px; 960x512, 5 DDIM steps, injected noise) against
     oracle/acv_oracle.py with the contract's own numbers: per step |EPE_hip - EPE_oracle| < 1e-4 and |d disp| <= 1e-3 px

@@ -91,6 +91,21 @@ def test_no_asm_valu_result_is_read_by_an_mfma_too_early(name, tmp_path):
     assert not m0["bad"], m0["bad"][:5]
 
 
+def test_m0_wait_state_in_the_persistent_deconv(tmp_path):
+    """csrc/deconv3d_pl.hip issues its skip-tile LDS-DMA from inline asm too: the M0 rule on its compiled stream (the loader
+    waves' DMAs come from the builtin, whose M0 writes the compiler guards itself)."""
+    src = ROOT / "diffuvolume_amd" / "csrc" / "deconv3d_pl.hip"
+    out = tmp_path / "deconv3d_pl.s"
+    flags = [f for f in _build.FLAGS if f != "-fPIC"]
+    r = subprocess.run([_build._hipcc(), *flags, "-S", "--cuda-device-only", str(src), "-o", str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m0 = {}
+    lint(out.read_text(), m0)
+    assert m0["n_dma"] >= 6 * 2 + 2 * 3, m0["n_dma"]     # skip-tile pieces of the three SKIP instantiations + the loaders' pieces
+    assert not m0["bad"], m0["bad"][:5]
+
+
 def test_lint_catches_the_hazard():
     text = """
 	;;#ASMSTART

@@ -26,10 +26,20 @@ B, H, W = 8, 512, 960
 
 
 class Stages:
-    def __init__(self):
-        self.ev, self.order = {}, []
+    """``roof=True``: every stage runs under its own KernelTimer (a HIP-event pair around every kernel launch of the library),
+    so that a stage carries the algorithmic flops / bytes and the matrix-pipe flops its kernels issue -- its own roofline."""
+
+    def __init__(self, roof=False):
+        self.ev, self.order, self.roof, self.kt = {}, [], roof, {}
 
     def run(self, name, fn):
+        if self.roof:
+            from diffuvolume_amd.profiling import KernelTimer
+            KernelTimer.active = self.kt.setdefault(name, KernelTimer())
+            try:
+                return fn()
+            finally:
+                KernelTimer.active = None
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         out = fn()
@@ -72,6 +82,7 @@ def main():
     st = Stages()
 
     def test_sample():
+        nonlocal st
         with torch.no_grad():
             origin.prepare(check_weights=True)
             fl = st.run("origin: feature CNN (left)", lambda: origin.feature_extraction(left)["gwc_feature"])
@@ -116,7 +127,32 @@ def main():
         plain()
     torch.cuda.synchronize()
     wall_plain = (time.perf_counter() - t0) / reps * 1e3
+    # per-stage rooflines: one more pass with a HIP-event pair around every kernel (kernel times only; slower than the
+    # stage times above by the event overhead, so the fractions are computed from THIS pass's kernel times)
+    PEAK_TF, PEAK_GBS = 157.3, 8000.0
+    rs = Stages(roof=True)
+    st_saved = st
+    st = rs
+    test_sample()
+    st = st_saved
+    roof = {}
+    for name, kt in rs.kt.items():
+        ks = kt.summary()
+        ms = sum(v["total_ms"] for v in ks.values())
+        if ms <= 0:
+            continue
+        fl, iss, by = (sum(v[k] for v in ks.values()) for k in ("flops", "issued_flops", "bytes"))
+        top = max(ks, key=lambda k: ks[k]["total_ms"])
+        roof[name] = {"kernel_ms": round(ms, 3), "launches": sum(v["launches"] for v in ks.values()),
+                      "algorithmic_tflops": round(fl / ms / 1e9, 1), "issued_frac_of_mfma_f32_peak": round(iss / ms / 1e9 / PEAK_TF, 3),
+                      "algorithmic_gb_s": round(by / ms / 1e6, 0), "frac_of_hbm_peak": round(by / ms / 1e6 / PEAK_GBS, 3),
+                      "bound": "mfma" if iss / ms / 1e9 / PEAK_TF > by / ms / 1e6 / PEAK_GBS else "hbm",
+                      "largest_kernel": top, "largest_kernel_share": round(ks[top]["total_ms"] / ms, 2)}
     out = {"batch": B, "size": [H, W], "stages_ms": {k: round(v, 3) for k, v in tab.items()}, "sum_of_stages_ms": round(total, 2),
+           "stage_rooflines": roof,
+           "stage_rooflines_note": "per stage: sum over its kernel launches of algorithmic flops / bytes and of the flops the matrix "
+                                   "pipe really issues (Winograd / polyphase forms issue 2.25x / 1.44x fewer), over the HIP-event "
+                                   "time of those launches; peaks 157.3 TFLOP/s (fp32 MFMA) and 8 TB/s",
            "wall_ms_with_stage_events": round(wall, 2), "wall_ms_public_forwards": round(wall_plain, 2),
            "host_gap_ms": round(wall - total, 2), "pairs_per_s": round(B / (wall_plain * 1e-3), 2)}
     os.makedirs(ROOT / "gpurun_out", exist_ok=True)

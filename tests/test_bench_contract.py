@@ -65,3 +65,12 @@ def test_calibrated_network_meets_the_raw_bars_on_all_pixels():
     assert all(s["frac_gt_1e-3"] <= p["bars"]["frac"] and s["epe_delta"] < p["bars"]["epe"] for s in p["teacher_forced"])
     if sum(s["flips_mask_zero"] for s in p["free_run"]) == 0:
         assert all(s["frac_gt_1e-3"] <= p["bars"]["frac"] for s in p["free_run"])
+
+
+def test_design_kernel_table_is_the_newest_bench_record():
+    """DESIGN.md's kernel table is generated from the newest profiles/r*_bench.json (tools/design_kernel_table.py): the
+    numbers in the document cannot drift from the committed record."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "design_kernel_table.py"), "--check"])
+    assert r.returncode == 0, "run python tools/design_kernel_table.py"

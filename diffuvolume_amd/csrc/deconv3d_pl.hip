@@ -7,7 +7,8 @@
 // What is different from deconv3d.hip's one-tile blocks (its in-kernel stamps: 21.5 % of a block's life is epilogue, 11 %
 // first fetch + commit phases, and the CU's partner block fills those at the rate of one wave per SIMD):
 //   * the MFMA waves only read LDS, issue MFMAs and store; bricks and weight images arrive by LDS-DMA from loader waves
-//     (`buffer_load_dwordx4 ... lds`, the range check writes the zero padding), double-buffered, one block barrier per step;
+//     (`buffer_load_dwordx4 ... lds`, the range check writes the zero padding), double-buffered, one block barrier per step
+//     (a layer with ONE block of output channels keeps one ring of four weight images for both groups instead);
 //   * a wave holds 64 accumulators (one input row x 16 positions x 32 output channels x 8 classes) instead of 128, so
 //     twelve waves of <= 168 registers fit a CU;
 //   * the eight MFMA waves are two GROUPS of four (a group = one tile of 1 x 2 x 32 input positions = 2 x 4 x 64 outputs
@@ -98,7 +99,7 @@ template <bool SKIP, bool RES, int AM>
 __global__ __launch_bounds__(512 + 64 * pl::NL, 1) void deconv3d_pl_kernel(PLArgs a) {
   using namespace pl;
   // (separate arrays: the MFMA waves' own LDS-DMA goes to sk_s only)
-  __shared__ __attribute__((aligned(16))) float w_s[2][2][W_FLOATS];        // [group][buffer]
+  __shared__ __attribute__((aligned(16))) float w_s[4][W_FLOATS];           // [group][buffer], or ONE ring of four (shared)
   __shared__ __attribute__((aligned(16))) float in_s[2][2][BRICK_FLOATS];
   __shared__ __attribute__((aligned(16))) float sk_s[8][SK_FLOATS];
   // BN scale / bias of every output channel.  They are read per tile; as vector-memory loads they would share the counter
@@ -166,6 +167,9 @@ __global__ __launch_bounds__(512 + 64 * pl::NL, 1) void deconv3d_pl_kernel(PLArg
   const int nchunk = a.Cin / KC;
   const int PERIOD = nchunk + NE;                      // steps of a tile: its chunks, then the epilogue halves
   const int n_total = my_pairs * PERIOD + NE;          // group 1 runs NE steps behind group 0
+  // one block of output channels: both groups walk the SAME weight chunks, NE steps apart -> one ring of four images, copied once
+  // (-1 % on the 64 -> 32 layer: 27 instead of 54 weight pieces per step)
+  const bool shared = a.nco == 1;
 
   // Barrier protocol (all twelve waves): P, then one per step.  In step s a computing group reads the buffers of its chunk
   // (its compute steps alternate between the two); the loaders copy what step s + 1 needs into the buffers step s does not
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(512 + 64 * pl::NL, 1) void deconv3d_pl_kernel(PLArg
         so[i] = ok ? (unsigned)cl * vol_bytes + (unsigned)((z * a.H + y) * a.W + x) * 4u : 0xfffffff0u;
       }
     };
-    auto dma = [&](const PLTile& t, const unsigned (&so)[NB], int c, float* bdst, float* wdst) __attribute__((always_inline)) {
+    auto dma = [&](const PLTile& t, const unsigned (&so)[NB], int c, float* bdst, float* wdst, bool with_w) __attribute__((always_inline)) {
       const uint64_t ba = reinterpret_cast<uint64_t>(a.in + ((size_t)t.b * a.Cin + (size_t)c * KC) * vol);
       const uint64_t bu = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ba) |
                           ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ba >> 32)) << 32);
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(512 + 64 * pl::NL, 1) void deconv3d_pl_kernel(PLArg
       const int wbase = (c * a.nco + t.tcb) * (W_FLOATS * 4);
 #pragma unroll
       for (int i = 0; i < NW; ++i)
-        if (li + NL * i < W_P)
+        if (with_w && li + NL * i < W_P)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(wdst + (li + NL * i) * 256), 16,
                                                    lane * 16, wbase + (li + NL * i) * 1024, 0, 0);
     };
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(512 + 64 * pl::NL, 1) void deconv3d_pl_kernel(PLArg
       for (int g = 0; g < 2; ++g) {
         if (s1 < g * NE || fk[g] >= my_pairs) continue;
         if (fp[g] < nchunk) {
-          if (ft[g].valid) dma(ft[g], sob[g], fp[g], in_s[g][fcc[g] & 1], w_s[g][fcc[g] & 1]);
+          if (ft[g].valid) dma(ft[g], sob[g], fp[g], in_s[g][fcc[g] & 1], w_s[shared ? (fcc[g] & 3) : 2 * g + (fcc[g] & 1)], !shared || g == 0);
           ++fcc[g];
         }
         if (++fp[g] == PERIOD) {
@@ -287,14 +291,14 @@ __global__ __launch_bounds__(512 + 64 * pl::NL, 1) void deconv3d_pl_kernel(PLArg
   };
 
   // ---- one chunk of 8 input channels: 27 taps x 2 k-steps x 2 channel halves, then the redir k-step of this chunk ----
-  auto compute = [&](int c, int buf) __attribute__((always_inline)) {
+  auto compute = [&](int c, int buf, int wslot) __attribute__((always_inline)) {
     // (the redir code is NOT wrapped in a run-time `c < nsk`: the load of `bw` and the wait for it must lie on ONE path, or
     // the compiler has to assume a pending load into those registers ever after and puts s_waitcnt vmcnt(0) -- which also
     // drains the stores -- in front of every later write to them.  A chunk beyond the skip channels copies zeros -- the
     // range check -- and multiplies them: for the hourglass layers every chunk carries skip channels.)
     const bool has_sk = c < nsk;
     const float* ib = in_s[g][buf] + a_off;
-    const float* wbp = w_s[g][buf] + lane * 4;
+    const float* wbp = w_s[wslot] + lane * 4;
     float bw[NT];
     if (SKIP) {
       const uint64_t ba = reinterpret_cast<uint64_t>(a.skip + (size_t)cur.b * a.Cskip * ovol);
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(512 + 64 * pl::NL, 1) void deconv3d_pl_kernel(PLArg
   for (int s = 0; s < n_total; ++s) {
     if (s >= g * NE && k < my_pairs) {
       if (p < nchunk) {
-        if (cur.valid) compute(p, cc & 1);
+        if (cur.valid) compute(p, cc & 1, shared ? (cc & 3) : 2 * g + (cc & 1));
         ++cc;
       } else if (p == nchunk) {                          // (NE == 2: the output planes pz = 0, then pz = 1)
         epilogue(std::integral_constant<int, 0>{});

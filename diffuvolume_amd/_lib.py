@@ -56,6 +56,10 @@ SIGNATURES = {
     "dv_conv3d_wino_packed_floats": (c_size_t, [I, I]),
     "dv_conv3d_wino_pack_weights_f32": (c_int, [P, P, I, I, P]),
     "dv_conv3d_wino_f32": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "dv_conv3d_wino3_packed_floats": (c_size_t, [I, I]),
+    "dv_conv3d_wino3_supported": (c_int, [I, I, I, I, I]),
+    "dv_conv3d_wino3_pack_weights_f32": (c_int, [P, P, I, I, P]),
+    "dv_conv3d_wino3_f32": (c_int, [P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "dv_conv3d_s2pp_supported": (c_int, [I, I, I, I, I]),
     "dv_conv3d_s2pp_packed_floats": (c_size_t, [I, I]),
     "dv_conv3d_s2pp_pack_weights_f32": (c_int, [P, P, I, I, P]),

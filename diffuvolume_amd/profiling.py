@@ -36,6 +36,7 @@ class KernelTimer:
 
 S2PP_MULT_REDUCTION = 1.44     # polyphase F(2,2) stride-2 form: 25 multiplies per 2x2 outputs and (depth tap, channel) instead of 36
 WINO_MULT_REDUCTION = 2.25     # F(2x2,3x3): 16 multiplies per 2x2 outputs and (depth tap, channel) instead of 36
+WINO3_MULT_REDUCTION = 3.375   # F(2x2x2,3x3x3): 64 multiplies per 2x2x2 outputs and channel instead of 216
 
 
 def timed(tag: str, flops: float, nbytes: float, fn: Callable[[], None], issued: float = 0.0, valu: float = 0.0) -> None:

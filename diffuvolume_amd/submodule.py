@@ -18,7 +18,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from .profiling import S2PP_MULT_REDUCTION, WINO_MULT_REDUCTION, timed
+from .profiling import S2PP_MULT_REDUCTION, WINO3_MULT_REDUCTION, WINO_MULT_REDUCTION, timed
 
 __all__ = ["build_gwc_volume", "build_concat_volume", "build_concat_attention_volume", "AttentionConcatVolume",
            "volume_factors",
@@ -356,6 +356,12 @@ class Conv3dPlan:
     implicit-GEMM kernel: weights repacked once on the device, BN folded to a
     per-channel scale/bias applied in the epilogue (submodule.py:94-97)."""
 
+    # 3x3x3 stride-1 layers: the F(2x2x2,3x3x3) kernel (False: the in-plane F(2x2,3x3) kernel everywhere; tests / A-B runs)
+    # from WINO3_MIN_CIN input channels on -- measured at batch 8 (tools/ab_wino3.py): 64 -> 64 -6.5 %, 128 -> 128 -7.5 %,
+    # 32 -> 32 +1.5 % (eight chunks do not amortise a block's prologue and depth exchange)
+    WINO3 = True
+    WINO3_MIN_CIN = 64
+
     def __init__(self, weight: torch.Tensor, bn: Optional[Tuple[torch.Tensor, ...]] = None,
                  stride: int = 1, act: int = ACT_NONE, bias: Optional[torch.Tensor] = None,
                  eps: float = 1e-5, precision: Optional[str] = None):
@@ -391,6 +397,12 @@ class Conv3dPlan:
                 _lib.check(lib.dv_conv3d_wino_pack_weights_f32(w.data_ptr(), self.wpacked.data_ptr(), self.cin,
                                                                self.cout, _lib.stream_ptr()),
                            "dv_conv3d_wino_pack_weights_f32")
+                # the F(2x2x2,3x3x3) image (csrc/conv3d_wino3.hip): every call without a filter prologue
+                self.wpacked3 = torch.empty(lib.dv_conv3d_wino3_packed_floats(self.cin, self.cout), dtype=torch.float32,
+                                            device=w.device)
+                _lib.check(lib.dv_conv3d_wino3_pack_weights_f32(w.data_ptr(), self.wpacked3.data_ptr(), self.cin,
+                                                                self.cout, _lib.stream_ptr()),
+                           "dv_conv3d_wino3_pack_weights_f32")
             elif self.split:
                 nbytes = lib.dv_conv3d_f16x3_packed_bytes(self.cin, self.cout)
                 self.wpacked = torch.empty(nbytes // 2, dtype=torch.float16, device=w.device)
@@ -443,6 +455,15 @@ class Conv3dPlan:
                                                                  b, cin, d, h, w, self.cout,
                                                                  self.act, _lib.stream_ptr()),
                                          "dv_conv3d_f16x3_f32"))
+                return out
+            if self.wino and self.WINO3 and cin >= self.WINO3_MIN_CIN and in_scale is None and x.data_ptr() % 16 == 0 and \
+                    lib.dv_conv3d_wino3_supported(cin, self.cout, d, h, w):
+                timed(f"conv3d_k3s1_co{self.cout}", 2.0 * out.numel() * cin * 27, nb,
+                      lambda: _lib.check(lib.dv_conv3d_wino3_f32(x.data_ptr(), self.wpacked3.data_ptr(),
+                                                                 _lib.ptr(self.scale), _lib.ptr(self.shift),
+                                                                 _lib.ptr(residual), out.data_ptr(), b, cin, d, h, w,
+                                                                 self.cout, self.act, _lib.stream_ptr()),
+                                         "dv_conv3d_wino3_f32"), issued=2.0 * out.numel() * cin * 27 / WINO3_MULT_REDUCTION)
                 return out
             if self.wino:
                 timed(f"conv3d_k3s1_co{self.cout}" + ("" if in_scale is None else "_filter"),

@@ -144,6 +144,20 @@ int dv_conv3d_wino_f32(const float* in, const float* wpacked, const float* ch_sc
                        const float* in_scale, const float* residual, float* out,
                        int B, int Cin, int D, int H, int W, int Cout, int act, dv_stream_t stream);
 
+/* The same layer with ALL THREE taps by minimal filtering, F(2x2x2,3x3x3) (csrc/conv3d_wino3.hip): 8 instead of 12
+ * multiplies per output and input channel, the depth positions of the transform on the four waves of a block (they meet in
+ * LDS after the channel loop).  fp32 operands and accumulation on v_mfma_f32_16x16x4_f32; the transforms only add /
+ * subtract, measured error no larger than the in-plane form's (tools/probes/wino_f222_numerics.py).  No filter prologue
+ * (a call with `in_scale` takes dv_conv3d_wino_f32).  dv_conv3d_wino3_supported: 1 when four channel volumes of the
+ * input fit 31-bit byte offsets. */
+size_t dv_conv3d_wino3_packed_floats(int Cin, int Cout);
+int dv_conv3d_wino3_supported(int Cin, int Cout, int D, int H, int W);
+int dv_conv3d_wino3_pack_weights_f32(const float* w /*[Cout,Cin,3,3,3]*/, float* wpacked, int Cin, int Cout,
+                                     dv_stream_t stream);
+int dv_conv3d_wino3_f32(const float* in, const float* wpacked, const float* ch_scale, const float* ch_bias,
+                        const float* residual, float* out, int B, int Cin, int D, int H, int W, int Cout, int act,
+                        dv_stream_t stream);
+
 /* The 3x3x3 STRIDE-2 layer (hourglass conv1 / conv3: acv_ddim.py:60,:66; pwcnet_ddim.py:137-147) in its polyphase
  * minimal-filtering form (csrc/conv3d_s2pp.hip): per in-plane axis the odd input phase sees a 2-tap filter, done as
  * F(2,2), the even phase one tap -- 25 instead of 36 multiplies per 2x2 outputs, depth taps direct, still on

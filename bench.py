@@ -46,16 +46,18 @@ DOMINANT_KERNEL = "conv3d_wino_kernel<false, 1, 0>"
 DOMINANT_TAGS = ("conv3d_k3s1_co32",)
 WINO_MULT_REDUCTION = 2.25        # F(2x2,3x3) in-plane: 16 multiplies per 2x2 outputs and depth tap instead of 36
 S2PP_MULT_REDUCTION = 1.44        # polyphase F(2,2) stride-2 form: 25 instead of 36
+WINO3_MULT_REDUCTION = 3.375      # F(2x2x2,3x3x3): 64 multiplies per 2x2x2 outputs instead of 216
 # the next kernels by time: (KernelTimer tags, rocprofv3 kernel name, issued-flop divisor).  The 64- and 128-channel
-# layers run the 4 x 4- and 8 x 2-tile instantiations of the same template (120- and 60-wide planes, no padding).
+# layers run the F(2x2x2,3x3x3) kernel (round 6, csrc/conv3d_wino3.hip): 4 x 4 tiles per wave on the 120-wide planes, 2 x 8
+# on the 60-wide ones (padded to 64: narrow tiles stage more surplus columns than the padding costs).
 SIDE_KERNELS = [
     # transposed convolution + fused redir (round 6): persistent, 8 MFMA waves in two groups + 4 loader waves per CU
     (("deconv3d_k3s2_redir",), "deconv3d_pl_kernel<true, false, 0>", 1.0),
     # stride 2 (round 5): the polyphase minimal-filtering kernel, 8 x 8-output patches, persistent with loader waves; it
     # issues 1.44 x fewer multiplies than the direct count (25 instead of 36 per 2 x 2 outputs and depth tap)
     (("conv3d_k3s2_co64", "conv3d_k3s2_co128"), "conv3d_s2pp_kernel<1>", S2PP_MULT_REDUCTION),
-    (("conv3d_k3s1_co64",), "conv3d_wino_kernel<false, 1, 1>", WINO_MULT_REDUCTION),
-    (("conv3d_k3s1_co128",), "conv3d_wino_kernel<false, 1, 2>", WINO_MULT_REDUCTION),
+    (("conv3d_k3s1_co64",), "conv3d_wino3_kernel<1>", WINO3_MULT_REDUCTION),
+    (("conv3d_k3s1_co128",), "conv3d_wino3_kernel<0>", WINO3_MULT_REDUCTION),
 ]
 
 

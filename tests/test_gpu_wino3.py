@@ -13,7 +13,14 @@ from diffuvolume_amd.synth import _gen
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-S.Conv3dPlan.WINO3_MIN_CIN = 1      # every layer on the kernel under test
+
+
+@pytest.fixture(autouse=True)
+def _every_layer_on_the_kernel_under_test():
+    old = S.Conv3dPlan.WINO3_MIN_CIN
+    S.Conv3dPlan.WINO3_MIN_CIN = 1
+    yield
+    S.Conv3dPlan.WINO3_MIN_CIN = old
 F = torch.nn.functional
 ACT = {"relu": S.ACT_RELU, "mish": S.ACT_MISH, "leaky": S.ACT_LEAKY, "none": S.ACT_NONE}
 

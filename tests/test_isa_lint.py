@@ -91,6 +91,22 @@ def test_no_asm_valu_result_is_read_by_an_mfma_too_early(name, tmp_path):
     assert not m0["bad"], m0["bad"][:5]
 
 
+def test_no_asm_valu_result_is_read_by_an_mfma_too_early_in_the_3d_winograd_kernel(tmp_path):
+    """csrc/conv3d_wino3.hip: the two 14-instruction transform bursts (depth combination + rows + columns) are inline asm
+    whose results are MFMA A operands; it has no LDS-DMA (weights and bricks travel through registers)."""
+    src = ROOT / "diffuvolume_amd" / "csrc" / "conv3d_wino3.hip"
+    out = tmp_path / "conv3d_wino3.s"
+    flags = [f for f in _build.FLAGS if f != "-fPIC"]
+    r = subprocess.run([_build._hipcc(), *flags, "-S", "--cuda-device-only", str(src), "-o", str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m0 = {}
+    bad, n_prod, n_mfma = lint(out.read_text(), m0)
+    assert n_prod >= 3 * 2 * 14 and n_mfma >= 3 * 64, (n_prod, n_mfma)
+    assert not bad, bad[:5]
+    assert m0["n_dma"] == 0, m0
+
+
 def test_m0_wait_state_in_the_persistent_deconv(tmp_path):
     """csrc/deconv3d_pl.hip issues its skip-tile LDS-DMA from inline asm too: the M0 rule on its compiled stream (the loader
     waves' DMAs come from the builtin, whose M0 writes the compiler guards itself)."""

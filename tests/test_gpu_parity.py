@@ -363,17 +363,30 @@ def test_aggregation_cost_parity(model, acv_state_dict):
     assert e_hip < 3 * e_ref, (e_hip, e_ref)
 
 
-def test_model_predictions_golden(model):
-    """One volume-filter step: disparity within 1e-3 px of the reference on 99.9 % of the pixels and
-    ~1e-4 px on average (north-star bar).  The soft-argmax amplifies cost error by the spread of the
-    distribution, |d disp| <= unc * max|d cost|; with random weights the spread is large, hence the
-    separate bars for the mean, the 99th percentile and the tail."""
+def test_model_predictions_golden(model, acv_state_dict):
+    """One volume-filter step against the reference's own fp32 output AND against a float64 evaluation of the same step
+    (oracle/acv_oracle.py in float64): north-star bars -- disparity within 1e-3 px, EPE within 1e-4.
+    The soft-argmax amplifies cost error by the spread of the distribution, |d disp| <= unc * max|d cost|; with random
+    weights the spread is large, and the reference's fp32 output is itself up to 9.5e-4 px from the float64 value.  So:
+      * against float64 (the value both fp32 paths approximate): EVERY pixel within 1e-3 px, and a mean error no larger
+        than 1.1 x the reference's own (measured: reference 6.8e-5 mean / 9.5e-4 max; HIP 6.8e-5 / 7.0e-4);
+      * against the reference's fp32 output, i.e. between two fp32 evaluations whose errors can have opposite signs:
+        mean < 2e-4, 99th percentile < 1e-3, no pixel beyond 2e-3, at most 0.25 % of the pixels beyond 1e-3 (measured
+        8.6e-5 / 5.7e-4 / 1.5e-3 / 0.11 %; with the in-plane Winograd kernel in every layer 8.4e-5 / 5.4e-4 / 1.4e-3 /
+        0.085 % -- the F(2x2x2) kernel of the 64- and 128-channel layers is the more accurate one against float64,
+        tests/test_gpu_wino3.py, but lands on the other side of the reference on two more of the 8 192 pixels)."""
     g = load_golden("model_predictions")
     pn, xs, pred, handle = model.model_predictions(dev(_volume(g["vol_seed"])), dev(g["x_T"]), dev(g["t"]))
     assert pn.dtype == torch.float64 and xs.dtype == torch.float32
     d = (pred.cpu() - g["pred"]).abs()
-    # north-star bars against the reference's own output: 99.9 % of the pixels within 1e-3 px, EPE within 1e-4
-    assert float(d.mean()) < 2e-4 and float((d > 1e-3).float().mean()) <= 1e-3, (float(d.mean()), float(d.max()))
+    assert float(d.mean()) < 2e-4 and float(d.max()) < 2e-3 and float((d > 1e-3).float().mean()) <= 2.5e-3, \
+        (float(d.mean()), float(d.max()), float((d > 1e-3).float().mean()))
+    orc64 = O.ACVDiffusionOracle(_f64_state_dict(acv_state_dict))
+    _, _, d64, _ = orc64.model_predictions(_volume(g["vol_seed"]).double(), g["x_T"], g["t"])
+    e_hip, e_ref = (pred.cpu().double() - d64).abs(), (g["pred"].double() - d64).abs()
+    assert float(e_ref.max()) < 1e-3                      # (the fixture: the reference itself is inside the bar)
+    assert float(e_hip.max()) < 1e-3, float(e_hip.max())
+    assert float(e_hip.mean()) <= 1.1 * float(e_ref.mean()), (float(e_hip.mean()), float(e_ref.mean()))
     gt = g["used0"].reshape(g["pred"].shape)             # EPE against the fixture's origin disparity
     assert abs(float((pred.cpu() - gt).abs().mean()) - float((g["pred"] - gt).abs().mean())) < 1e-4
     p99 = float(d.flatten().quantile(0.99))
@@ -459,8 +472,9 @@ def test_ddim_sample_golden(model, acv_state_dict):
     d = (stack.cpu() - g["stack"]).abs()
     for i in range(1, 6):
         assert float(d[i].median()) < 1e-4, (i, float(d[i].median()))
-    assert float(d[1].mean()) < 2e-4 and float((d[1] > 1e-3).float().mean()) <= 1e-3, \
-        (float(d[1].mean()), float((d[1] > 1e-3).float().mean()))
+    # (step 1 is test_model_predictions_golden's step: two fp32 evaluations, each within 1e-3 px of the float64 one)
+    assert float(d[1].mean()) < 2e-4 and float(d[1].max()) < 2e-3 and float((d[1] > 1e-3).float().mean()) <= 2.5e-3, \
+        (float(d[1].mean()), float(d[1].max()), float((d[1] > 1e-3).float().mean()))
     rep = _assert_loop_contract(model, acv_state_dict, vol, g["used"], g["x_T"], g["tape_seed"])
     print("ddim_sample fixture:", rep)
     for i, (e_h, e_o) in enumerate(_teacher_forced_vs_fp64(model, acv_state_dict, vol, g["used"], g["x_T"], g["tape_seed"])):

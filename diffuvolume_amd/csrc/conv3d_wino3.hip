@@ -108,12 +108,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_wino3_kernel(W3Args a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = depth position a of the transform
   const int j = lane & 15, kq = lane >> 4;
 
+  // the output-channel block is the SLOWEST tile index: an XCD's slab of the tile order (dv_xcd_remap) then works with one
+  // block's weights (1 MB of the 128 -> 128 layer's 4 MB image: the whole image does not stay in a 4-MB L2 beside the
+  // bricks -- 1.23 GB of HBM traffic per launch for 0.19 GB of tensors, -2.4 % with this order); the bricks the
+  // output-channel blocks share come from the Infinity Cache
   unsigned t = dv_xcd_remap(blockIdx.x, gridDim.x);
-  const int tc = t % a.nco; t /= a.nco;
   const int tx = t % a.ntx; t /= a.ntx;
   const int ty = t % a.nty; t /= a.nty;
-  const int tz = t % a.ntz;
-  const int b = t / a.ntz;
+  const int tz = t % a.ntz; t /= a.ntz;
+  const int b = t % a.B;
+  const int tc = t / a.B;
   const int x0 = tx * TW, y0 = ty * TH, z0 = tz * TD, co0 = tc * 32;
 
   // (not zeroed: the first chunk's MFMAs take the inline constant 0 as their C operand)

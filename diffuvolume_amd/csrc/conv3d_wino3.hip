@@ -87,6 +87,7 @@ struct W3Args {
   float* out;
   int B, Cin, D, H, W, Cout;
   int ntx, nty, ntz, nco;
+  int tc_slow;           // tile order: output-channel block slowest (see the kernel)
   int act;
   int fast_ok;           // W % 4 == 0, 16-byte aligned pointers
 };
@@ -108,16 +109,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_wino3_kernel(W3Args a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = depth position a of the transform
   const int j = lane & 15, kq = lane >> 4;
 
-  // the output-channel block is the SLOWEST tile index: an XCD's slab of the tile order (dv_xcd_remap) then works with one
-  // block's weights (1 MB of the 128 -> 128 layer's 4 MB image: the whole image does not stay in a 4-MB L2 beside the
-  // bricks -- 1.23 GB of HBM traffic per launch for 0.19 GB of tensors, -2.4 % with this order); the bricks the
-  // output-channel blocks share come from the Infinity Cache
+  // tile order.  tc_slow (the host sets it when the layer's whole input fits the Infinity Cache): the output-channel block
+  // is the SLOWEST index, so an XCD's slab of the tile order (dv_xcd_remap) works with one block's weights (1 MB of the
+  // 128 -> 128 layer's 4-MB image, which does not stay in a 4-MB L2 beside the bricks: 1.23 GB of HBM traffic per launch
+  // for 0.19 GB of tensors, 0.78 GB and -2.4 % with this order) and the bricks the blocks share come from the Infinity
+  // Cache.  Otherwise the output-channel blocks of a tile are neighbours and share its bricks in one L2.
   unsigned t = dv_xcd_remap(blockIdx.x, gridDim.x);
+  int tc = 0;
+  if (!a.tc_slow) { tc = t % a.nco; t /= a.nco; }
   const int tx = t % a.ntx; t /= a.ntx;
   const int ty = t % a.nty; t /= a.nty;
   const int tz = t % a.ntz; t /= a.ntz;
   const int b = t % a.B;
-  const int tc = t / a.B;
+  if (a.tc_slow) tc = t / a.B;
   const int x0 = tx * TW, y0 = ty * TH, z0 = tz * TD, co0 = tc * 32;
 
   // (not zeroed: the first chunk's MFMAs take the inline constant 0 as their C operand)
@@ -521,6 +525,7 @@ extern "C" int dv_conv3d_wino3_f32(const float* in, const float* wpacked, const 
     a.ntx = cdiv(W, G::TW); a.nty = cdiv(H, G::TH); a.ntz = cdiv(D, G::TD); a.nco = cdiv(Cout, 32);
     const long long blocks = (long long)B * a.nco * a.ntz * a.nty * a.ntx;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return (int)DV_ERR_SHAPE;
+    a.tc_slow = a.nco > 1 && (size_t)B * Cin * D * H * W * sizeof(float) <= ((size_t)128 << 20);   // (order only: same bits)
     hipLaunchKernelGGL((conv3d_wino3_kernel<SHAPE>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     return dv_launch_status();
   };

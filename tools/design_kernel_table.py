@@ -10,8 +10,8 @@ ROOT = Path(__file__).resolve().parents[1]
 BEGIN, END = "<!-- KERNEL_TABLE_BEGIN -->", "<!-- KERNEL_TABLE_END -->"
 WHAT = {
     "conv3d_k3s1_co32": ("Winograd 3×3×3 stride 1, 32→32 (20 launches per step)", "4b"),
-    "conv3d_k3s1_co64": ("same kernel, 64→64 (4×4 tiles)", "4b"),
-    "conv3d_k3s1_co128": ("same kernel, 128→128 (8×2 tiles)", "4b"),
+    "conv3d_k3s1_co64": ("Winograd F(2×2×2), 64→64 (4×4 tiles; issued = algorithmic / 3.375)", "4b′"),
+    "conv3d_k3s1_co128": ("Winograd F(2×2×2), 128→128 (2×8 tiles on the 60-wide plane)", "4b′"),
     "deconv3d_k3s2_redir": ("transposed convolution + fused redir, persistent with loader waves", "4e"),
     "conv3d_k3s2_co64": ("polyphase stride 2, 32→64", "4d"),
     "conv3d_k3s2_co128": ("polyphase stride 2, 64→128", "4d"),

@@ -1,8 +1,9 @@
-"""Fixed-seed subsets of the random-shape fuzzers (tools/fuzz_kernels.py, fuzz_round3.py, fuzz_round4.py, fuzz_round5.py) inside the driver's
+"""Fixed-seed subsets of the random-shape fuzzers (tools/fuzz_kernels.py, fuzz_round3.py .. fuzz_round6.py) inside the driver's
 `-m gpu` run: conv2d (direct / Winograd / dilated / stride 2 / cat / K-split), conv3d (both stride-1 tilings, stride 2 with
 and without the filter prologue and both tilings, single-channel head), transposed conv + redir, rank-1 layer incl. odd
 Cout, table build, patch stencils, attention-concat volume, the 2-D Winograd source modes / gate pair / K-split, the fused
-geometry lookup, `interp` -- each against float64 / MIOpen PyTorch statements on the GPU.
+geometry lookup, `interp` -- each against float64 / MIOpen PyTorch statements on the GPU; round 6: the F(2x2x2,3x3x3) kernel
+against the in-plane Winograd kernel and the persistent transposed convolution against the one-tile kernel (+ grid caps).
 The scripts seed their generators themselves, so a case count selects a reproducible prefix of their sequence; the full
 runs (40-80 cases) stay a tool."""
 import subprocess
@@ -18,7 +19,7 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parents[1]
 
 
-@pytest.mark.parametrize("script,cases", [("fuzz_kernels.py", 8), ("fuzz_round3.py", 8), ("fuzz_round4.py", 8), ("fuzz_round5.py", 12)])
+@pytest.mark.parametrize("script,cases", [("fuzz_kernels.py", 8), ("fuzz_round3.py", 8), ("fuzz_round4.py", 8), ("fuzz_round5.py", 12), ("fuzz_round6.py", 30)])
 def test_fuzzer_prefix(script, cases):
     r = subprocess.run([sys.executable, str(ROOT / "tools" / script), str(cases)], capture_output=True, text=True,
                        timeout=600, cwd=ROOT)
